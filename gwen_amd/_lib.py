@@ -1,0 +1,70 @@
+"""ctypes binding of libgwen_hip.so -- the only way gwen_amd reaches the GPU kernels.
+
+There is NO CPU fallback: if the shared library is missing or a launcher fails, a RuntimeError is
+raised (the reference's loops catch RuntimeError: /root/reference/src/gwen/models_gnn.py:389).
+The library handle lives in this module, never on an nn.Module, so modules stay picklable
+(``mp.spawn`` / ``mlflow.pytorch.log_model``: /root/reference/src/gwen/train_gnn.py:144-152,
+/root/reference/src/gwen/models_gnn.py:387).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgwen_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+# name -> (restype, argtypes); mirrors include/gwen_hip.h one to one
+SIGNATURES = {
+    "gwen_hip_version": (C.c_char_p, []),
+    "gwen_hip_error_string": (C.c_char_p, [_int]),
+    "gwen_gcn_prep_workspace_bytes": (_int, [_i64, _i64, C.POINTER(C.c_size_t)]),
+    "gwen_gcn_prep": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp, C.c_size_t, _vp]),
+    "gwen_gcn_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "gwen_gcn_propagate_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                      _i64, _i64, _int, _vp]),
+    "gwen_gcn_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
+    "gwen_gcn_grad_workspace_floats": (_i64, [_i64, _i64, _i64]),
+    "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "gwen_relu_backward_f32": (_int, [_vp, _vp, _vp, _i64, _vp]),
+}
+
+
+class GwenHipError(RuntimeError):
+    """A launcher of libgwen_hip.so returned non-zero."""
+
+
+def lib() -> C.CDLL:
+    """Load libgwen_hip.so (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: the HIP extension has not been built "
+                        "(run `python -m gwen_amd.build`); gwen_amd has no CPU fallback")
+                L = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)      # AttributeError if the ABI lost a symbol
+                    fn.restype, fn.argtypes = res, args
+                _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gwen_hip_error_string(rc).decode()
+        raise GwenHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def version() -> str:
+    return lib().gwen_hip_version().decode()

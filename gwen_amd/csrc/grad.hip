@@ -1,0 +1,148 @@
+// Backward pieces of the GCNConv layer (the reference trains through it:
+// /root/reference/src/gwen/models_gnn.py:372 loss.backward(), :373 optimizer.step()).
+//   grad_W = g^T @ x   reduction over the node axis, fp32 MFMA, two deterministic stages
+//   grad_b = column sums of g
+//   ReLU backward mask
+// (grad wrt the aggregated features is K2 on the transposed CSR; grad wrt x is K3 with W^T.)
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunkRows = 1024;   // rows reduced by one block before the cross-chunk stage
+
+// One wave = one 32x32 tile of grad_W (rows = output channel, cols = input channel) over one chunk
+// of node rows.  A[i = l&31][k = l>>5] = g[row k][o0 + i], B[k][j = l&31] = x[row k][i0 + j]:
+// both operands are 128-B contiguous global reads per half-wave, so no LDS staging is needed.
+__global__ __launch_bounds__(kThreads) void k_grad_w(const float *__restrict__ g,
+                                                     const float *__restrict__ x,
+                                                     float *__restrict__ dst, int64_t rows, int Fin,
+                                                     int Fout, int64_t ldg, int64_t ldx,
+                                                     int tiles_i, int ntiles) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.y * 4 + wave;
+  if (tile >= ntiles) return;
+  const int o0 = (tile / tiles_i) * 32, i0 = (tile % tiles_i) * 32;
+  const int64_t r0 = (int64_t)blockIdx.x * kChunkRows;
+  const int64_t r1 = (r0 + kChunkRows < rows) ? r0 + kChunkRows : rows;
+  const bool ao = o0 + li < Fout, ai = i0 + li < Fin;
+  const float *gp = g + o0 + li, *xp = x + i0 + li;
+  f32x16 acc = {};
+  for (int64_t r = r0 + lh; r < r1 + lh; r += 2) {     // every lane runs the same trip count
+    const bool in = r < r1;
+    const float a = (in && ao) ? gp[r * ldg] : 0.0f;
+    const float b = (in && ai) ? xp[r * ldx] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
+  if (!ai) return;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int o = o0 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+    if (o < Fout) d[(int64_t)o * Fin + i0 + li] = acc[t];
+  }
+}
+
+// dst[j] = sum over chunks c (ascending) of partial[c][j]
+__global__ void k_reduce_chunks(const float *__restrict__ partial, float *__restrict__ dst,
+                                int64_t count, int nchunks) {
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  float s = 0.0f;
+  for (int c = 0; c < nchunks; ++c) s = s + partial[(int64_t)c * count + j];
+  dst[j] = s;
+}
+
+// column sums of one chunk of rows: thread = column, 4 row phases per block folded through LDS
+__global__ __launch_bounds__(kThreads) void k_grad_b(const float *__restrict__ g,
+                                                     float *__restrict__ dst, int64_t rows, int F,
+                                                     int64_t ldg) {
+  __shared__ float red[kThreads];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), phase = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kChunkRows;
+  const int64_t r1 = (r0 + kChunkRows < rows) ? r0 + kChunkRows : rows;
+  float s = 0.0f;
+  if (c < F)
+    for (int64_t r = r0 + phase; r < r1; r += 4) s = s + g[r * ldg + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (phase == 0 && c < F)
+    dst[(int64_t)blockIdx.x * F + c] = ((red[threadIdx.x] + red[threadIdx.x + 64]) +
+                                        red[threadIdx.x + 128]) + red[threadIdx.x + 192];
+}
+
+__global__ void k_relu_bwd(const float *__restrict__ y, const float *__restrict__ g,
+                           float *__restrict__ gin, int64_t count) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < count) gin[i] = y[i] > 0.0f ? g[i] : 0.0f;
+}
+
+inline int64_t nchunks_for(int64_t rows) { return rows > 0 ? (rows + kChunkRows - 1) / kChunkRows : 1; }
+
+}  // namespace
+
+extern "C" int64_t gwen_gcn_grad_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout) {
+  const int64_t nc = nchunks_for(rows);
+  const int64_t w = nc > 1 ? nc * Fin * Fout : 0;
+  const int64_t b = nc > 1 ? nc * (Fout > Fin ? Fout : Fin) : 0;
+  return (w > b ? w : b) + 1;
+}
+
+extern "C" int gwen_gcn_grad_weight_f32(const float *g, const float *x, float *grad_W,
+                                        int64_t rows, int64_t Fin, int64_t Fout, int64_t ldg,
+                                        int64_t ldx, float *partial, gwen_stream_t stream_) {
+  if (rows < 0 || Fin < 0 || Fout < 0 || ldg < Fout || ldx < Fin) return GWEN_EINVAL;
+  if (Fin == 0 || Fout == 0) return GWEN_OK;
+  if (!grad_W || (rows > 0 && (!g || !x))) return GWEN_EINVAL;
+  if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
+  hipStream_t st = gwen_stream(stream_);
+  const int64_t nc = nchunks_for(rows);
+  const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
+  const int64_t ntiles = (int64_t)tiles_i * tiles_o;
+  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL) return GWEN_ERANGE;
+  if (nc > 1 && !partial) return GWEN_EINVAL;
+  float *dst = nc > 1 ? partial : grad_W;
+  dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
+  k_grad_w<<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i,
+                                      (int)ntiles);
+  GWEN_LAUNCH_CHECK();
+  if (nc > 1) {
+    const int64_t count = Fin * Fout;
+    k_reduce_chunks<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(partial, grad_W, count, (int)nc);
+    GWEN_LAUNCH_CHECK();
+  }
+  return GWEN_OK;
+}
+
+extern "C" int gwen_gcn_grad_bias_f32(const float *g, float *grad_b, int64_t rows, int64_t F,
+                                      int64_t ldg, float *partial, gwen_stream_t stream_) {
+  if (rows < 0 || F < 0 || ldg < F) return GWEN_EINVAL;
+  if (F == 0) return GWEN_OK;
+  if (!grad_b || (rows > 0 && !g)) return GWEN_EINVAL;
+  hipStream_t st = gwen_stream(stream_);
+  const int64_t nc = nchunks_for(rows);
+  if (nc > 1 && !partial) return GWEN_EINVAL;
+  if ((F + 63) / 64 > 65535 || nc > 0x7fffffffLL) return GWEN_ERANGE;
+  float *dst = nc > 1 ? partial : grad_b;
+  dim3 grid((unsigned)nc, (unsigned)((F + 63) / 64));
+  k_grad_b<<<grid, kThreads, 0, st>>>(g, dst, rows, (int)F, ldg);
+  GWEN_LAUNCH_CHECK();
+  if (nc > 1) {
+    k_reduce_chunks<<<(unsigned)((F + 255) / 256), 256, 0, st>>>(partial, grad_b, F, (int)nc);
+    GWEN_LAUNCH_CHECK();
+  }
+  return GWEN_OK;
+}
+
+extern "C" int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t count,
+                                      gwen_stream_t stream_) {
+  if (count < 0) return GWEN_EINVAL;
+  if (count == 0) return GWEN_OK;
+  if (!y || !g || !gin) return GWEN_EINVAL;
+  const int64_t blocks = (count + 255) / 256;
+  if (blocks > 0x7fffffffLL) return GWEN_ERANGE;
+  k_relu_bwd<<<(unsigned)blocks, 256, 0, gwen_stream(stream_)>>>(y, g, gin, count);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}

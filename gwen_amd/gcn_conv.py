@@ -1,0 +1,110 @@
+"""``GCNConv`` -- the drop-in for ``torch_geometric.nn.GCNConv`` as GWEN uses it.
+
+The replaceable unit of the reference is the class bound to the name ``GCNConv`` at
+/root/reference/src/gwen/models_gnn.py:19; it is constructed as ``GCNConv(in, out)`` (:118-130,
+:172-184) and called as ``conv(x, edge_index)`` (:147-149, :204-206).  Same constructor keywords,
+same parameter names (``bias`` then ``lin.weight`` -> identical ``state_dict`` keys, SURVEY
+Appendix B), same initialisation (glorot-uniform weight, zero bias), same error types.
+
+Differences, all deliberate:
+  * the normalised graph is prepared once per ``edge_index`` tensor (K1) and shared by every layer
+    (``cached`` therefore only controls whether this layer pins its own copy);
+  * forward runs on the HIP kernels only -- a CPU tensor raises ``RuntimeError`` (no fallback);
+  * ``forward(..., relu=True)`` fuses the activation GWEN applies right after each layer.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .graph import GraphCSR, default_cache
+from .ops import gcn_layer
+
+
+class Linear(nn.Module):
+    """Parameter holder matching PyG ``Linear(in, out, bias=False)``: one ``weight`` [out, in]."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        if self.weight.numel() > 0:                    # glorot: U(-a, a), a = sqrt(6/(fan_in+fan_out))
+            a = math.sqrt(6.0 / (self.weight.size(0) + self.weight.size(1)))
+            with torch.no_grad():
+                self.weight.uniform_(-a, a)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, bias=False"
+
+
+class GCNConv(nn.Module):
+    r"""``X' = D^-1/2 (A + I) D^-1/2 X W^T + b`` on MI355X.
+
+    Args mirror torch-geometric 2.3.1: ``in_channels, out_channels, improved=False, cached=False,
+    add_self_loops=True, normalize=True, bias=True``.
+    """
+
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False,
+                 cached: bool = False, add_self_loops: bool = True, normalize: bool = True,
+                 bias: bool = True, **kwargs):
+        kwargs.pop("aggr", None)
+        if kwargs:
+            raise TypeError(f"unsupported GCNConv arguments: {sorted(kwargs)}")
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached = improved, cached
+        self.add_self_loops, self.normalize = add_self_loops, normalize
+        self._cached_graph: Optional[GraphCSR] = None
+        self.order = "auto"                            # "auto" | "transform_first" | "aggregate_first"
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.lin = Linear(in_channels, out_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        self.lin.reset_parameters()
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+        self._cached_graph = None
+
+    # the prepared graph holds device tensors; never pickle it with the module
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_cached_graph"] = None
+        return state
+
+    def graph_for(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor]) -> GraphCSR:
+        n = x.size(-2)
+        if self.cached and self._cached_graph is not None:
+            return self._cached_graph
+        g = default_cache().get(edge_index, n, edge_weight, add_self_loops=self.add_self_loops,
+                                improved=self.improved, normalize=self.normalize)
+        if self.cached:
+            self._cached_graph = g
+        return g
+
+    def forward(self, x: Tensor, edge_index, edge_weight: Optional[Tensor] = None,
+                relu: bool = False) -> Tensor:
+        if not isinstance(x, Tensor):
+            raise TypeError("x must be a torch.Tensor")
+        if x.dim() not in (2, 3):
+            raise ValueError(f"x must be [N, C] or [members, N, C], got {tuple(x.shape)}")
+        if x.size(-1) != self.in_channels:
+            raise ValueError(f"x has {x.size(-1)} channels, layer expects {self.in_channels}")
+        if isinstance(edge_index, GraphCSR):
+            graph = edge_index
+        else:
+            graph = self.graph_for(x, edge_index, edge_weight)
+        return gcn_layer(x, self.lin.weight, self.bias, graph, relu=relu, order=self.order)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}"

@@ -1,0 +1,177 @@
+"""Graph preparation (K1) on the host side: run it once per graph, keep the CSR.
+
+The reference recomputes ``gcn_norm`` inside each of the six ``GCNConv`` calls of every forward
+(/root/reference/src/gwen/models_gnn.py:147-149,:204-206; constructors :118-184 leave
+``cached=False``) although normalisation depends on topology only.  Here the result is a
+``GraphCSR`` that every layer of a forward shares, cached on the *identity* of the ``edge_index``
+tensor object (weak reference + in-place version counter): a new tensor object -- e.g. each
+relabelled NeighborLoader batch of the reference's loops, models_gnn.py:351-360 -- is a miss even
+when the caching allocator hands back the same address, so a stale CSR can never be used.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device: torch.device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+@dataclass
+class GraphCSR:
+    """CSR by target node with completed self-loops (see include/gwen_hip.h, K1)."""
+
+    num_nodes: int
+    num_edges: int                 # E of the edge_index it was built from
+    rowptr: Tensor                 # int32 [N+1]
+    col: Tensor                    # int32 [E+N]   source node per stored entry
+    val: Tensor                    # fp32  [E+N]   normalised weight per stored entry
+    eid: Tensor                    # int32 [E+N]   original edge id, -1 for a completed loop
+    dis: Tensor                    # fp32  [N]     deg^-1/2
+    status: Tensor                 # int32 [2]     [bad-index flag, E']
+    _workspace: Optional[Tensor] = field(default=None, repr=False)
+    _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
+
+    @property
+    def device(self) -> torch.device:
+        return self.rowptr.device
+
+    def nnz(self) -> int:
+        """Number of stored entries E' (synchronises)."""
+        return int(self.status[1].item())
+
+    def transposed(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """CSR by SOURCE node (rowptr, col = target, val) for the backward pass; built on first use."""
+        if self._transposed is None:
+            n, cap = self.num_nodes, self.col.numel()
+            dev = self.device
+            t_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            t_col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            t_val = torch.empty(max(cap, 1), dtype=torch.float32, device=dev)
+            ws = self._workspace
+            if ws is None:
+                ws = _alloc_workspace(n, self.num_edges, dev)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().gwen_gcn_transpose(
+                    _ptr(self.rowptr), _ptr(self.col), _ptr(self.val), n, cap, _ptr(t_rowptr),
+                    _ptr(t_col), _ptr(t_val), _ptr(ws), ws.numel(), _stream(dev))
+            _lib.check(rc, "gwen_gcn_transpose")
+            self._transposed = (t_rowptr, t_col, t_val)
+        return self._transposed
+
+
+def _alloc_workspace(n: int, e: int, device: torch.device) -> Tensor:
+    nbytes = C.c_size_t(0)
+    _lib.check(_lib.lib().gwen_gcn_prep_workspace_bytes(n, e, C.byref(nbytes)),
+               "gwen_gcn_prep_workspace_bytes")
+    return torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=device)
+
+
+def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor] = None, *,
+                  add_self_loops: bool = True, improved: bool = False, normalize: bool = True,
+                  validate: bool = True) -> GraphCSR:
+    """Run K1 on the device holding ``edge_index`` (current stream) and return the CSR.
+
+    ``validate=True`` reads back one flag (a stream synchronisation) and raises ``IndexError`` when a
+    node index lies outside ``[0, num_nodes)`` -- what the reference's CPU path raises from
+    ``index_select``.  Pass ``validate=False`` to stay asynchronous (bad edges are then dropped).
+    """
+    if not isinstance(edge_index, Tensor):
+        raise TypeError("edge_index must be a torch.Tensor")
+    if edge_index.dtype != torch.int64:
+        raise TypeError(f"edge_index must be int64 (got {edge_index.dtype})")
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must have shape [2, E] (got {tuple(edge_index.shape)})")
+    if not edge_index.is_cuda:
+        raise RuntimeError("gwen_amd needs edge_index on a HIP device; there is no CPU fallback")
+    if num_nodes < 0:
+        raise ValueError("num_nodes must be >= 0")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    e = ei.size(1)
+    ew = None
+    if edge_weight is not None:
+        if edge_weight.dim() != 1 or edge_weight.numel() != e:
+            raise ValueError("edge_weight must have shape [E]")
+        if edge_weight.device != dev:
+            raise RuntimeError("edge_weight and edge_index are on different devices")
+        ew = edge_weight.detach().to(torch.float32).contiguous()
+    n = int(num_nodes)
+    cap = max(e + n, 1)
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(cap, dtype=torch.int32, device=dev)
+    val = torch.empty(cap, dtype=torch.float32, device=dev)
+    eid = torch.empty(cap, dtype=torch.int32, device=dev)
+    dis = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+    status = torch.empty(2, dtype=torch.int32, device=dev)
+    ws = _alloc_workspace(n, e, dev)
+    loops = bool(add_self_loops and normalize)      # loops are completed inside gcn_norm only
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_prep(
+            _ptr(ei), _ptr(ew), n, e, int(loops), 2.0 if improved else 1.0, int(normalize),
+            _ptr(rowptr), _ptr(col), _ptr(val), _ptr(eid), _ptr(dis), _ptr(status), _ptr(ws),
+            ws.numel(), _stream(dev))
+    _lib.check(rc, "gwen_gcn_prep")
+    g = GraphCSR(n, e, rowptr, col, val, eid, dis, status, _workspace=ws)
+    if validate and int(status[0].item()) != 0:
+        raise IndexError(f"edge_index holds node indices outside [0, {n})")
+    return g
+
+
+class GraphCache:
+    """Small LRU of prepared graphs keyed on tensor identity (see module docstring)."""
+
+    def __init__(self, capacity: int = 8):
+        self.capacity = capacity
+        self._d: "OrderedDict[tuple, tuple]" = OrderedDict()
+        self.hits = 0
+        self.misses = 0
+
+    def get(self, edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor], *,
+            add_self_loops: bool, improved: bool, normalize: bool) -> GraphCSR:
+        key = (id(edge_index), num_nodes, None if edge_weight is None else id(edge_weight),
+               add_self_loops, improved, normalize)
+        ent = self._d.get(key)
+        if ent is not None:
+            ei_ref, ei_ver, ew_ref, ew_ver, g = ent
+            same = ei_ref() is edge_index and ei_ver == edge_index._version
+            if edge_weight is not None:
+                same = same and ew_ref is not None and ew_ref() is edge_weight \
+                    and ew_ver == edge_weight._version
+            if same:
+                self._d.move_to_end(key)
+                self.hits += 1
+                return g
+            del self._d[key]
+        self.misses += 1
+        g = prepare_graph(edge_index, num_nodes, edge_weight, add_self_loops=add_self_loops,
+                          improved=improved, normalize=normalize)
+        self._d[key] = (weakref.ref(edge_index), edge_index._version,
+                        None if edge_weight is None else weakref.ref(edge_weight),
+                        None if edge_weight is None else edge_weight._version, g)
+        while len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+        return g
+
+    def clear(self) -> None:
+        self._d.clear()
+
+
+_default_cache = GraphCache()
+
+
+def default_cache() -> GraphCache:
+    return _default_cache

@@ -1,0 +1,121 @@
+"""GWEN's GNN model surface, same names as /root/reference/src/gwen/models_gnn.py.
+
+``GNNConfig`` (:86-103), ``DownConvLayers`` (:106-157), ``UpConvLayers`` (:160-212),
+``GCNConvLayers`` (:215-258), ``GNNModel`` (:268-303) and ``loss_func`` (:261-265), with identical
+attribute names, so a reference ``state_dict`` (20 tensors) loads with
+``strict=True`` in both directions and ``GNNModel.forward(x, edge_index)`` drops into the reference's
+train/eval loops (:365, :444).
+
+MI355X-side differences: the graph is prepared once per forward (not once per layer), the ReLU the
+reference applies after a layer is fused into that layer's last kernel, and ``x`` may carry a
+leading ensemble-member axis ``[members, N, C]`` that shares one prepared graph.
+The train/eval drivers, MLflow logging and NeighborLoader of the reference file are host
+orchestration and out of scope.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+
+import torch
+from torch import Tensor, nn
+
+from .gcn_conv import GCNConv
+from .graph import GraphCSR, default_cache
+
+logger = logging.getLogger("gwen_amd")
+
+
+@dataclass
+class GNNConfig(dict):
+    """Configuration parameters for the GNN model (models_gnn.py:86-103)."""
+
+    nodes_in: int
+    nodes_out: int
+    channels_in: int
+    channels_out: int
+    hidden_feats: int
+
+
+class DownConvLayers(nn.Module):
+    """conv1..conv5 declared, conv1..conv3 used (models_gnn.py:118-130, :147-151)."""
+
+    def __init__(self, gnn_configs: GNNConfig):
+        super().__init__()
+        h = gnn_configs.hidden_feats
+        self.conv1 = GCNConv(gnn_configs.channels_in, h)
+        self.conv2 = GCNConv(h, h // 2)
+        self.conv3 = GCNConv(h // 2, h // 4)
+        self.conv4 = GCNConv(h // 4, h // 8)
+        self.conv5 = GCNConv(h // 8, h // 16)
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        try:
+            x = self.conv1(x, edge_index, relu=True)
+            x = self.conv2(x, edge_index, relu=True)
+            x = self.conv3(x, edge_index, relu=True)
+        except Exception as e:
+            logger.error("Error occurred while performing forward pass in DownConvLayers: %s", e)
+            raise
+        return x
+
+
+class UpConvLayers(nn.Module):
+    """upconv1..upconv5 declared, upconv3..upconv5 used (models_gnn.py:172-184, :202-206)."""
+
+    def __init__(self, gnn_configs: GNNConfig):
+        super().__init__()
+        h = gnn_configs.hidden_feats
+        self.upconv1 = GCNConv(h // 16, h // 8)
+        self.upconv2 = GCNConv(h // 8, h // 4)
+        self.upconv3 = GCNConv(h // 4, h // 2)
+        self.upconv4 = GCNConv(h // 2, h)
+        self.upconv5 = GCNConv(h, gnn_configs.channels_out)
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        try:
+            x = self.upconv3(x, edge_index, relu=True)
+            x = self.upconv4(x, edge_index, relu=True)
+            x = self.upconv5(x, edge_index)
+        except Exception as e:
+            logger.error("Error occurred while performing forward pass in UpConvLayers: %s", e)
+            raise
+        return x
+
+
+class GCNConvLayers(nn.Module):
+    """down stack then up stack (models_gnn.py:235-236, :252-253)."""
+
+    def __init__(self, gnn_configs: GNNConfig):
+        super().__init__()
+        self.down_conv_layers = DownConvLayers(gnn_configs)
+        self.up_conv_layers = UpConvLayers(gnn_configs)
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        x = self.down_conv_layers(x, edge_index)
+        x = self.up_conv_layers(x, edge_index)
+        return x
+
+
+def loss_func(output: Tensor, target: Tensor, target_mask: Tensor) -> Tensor:
+    """L1 on the masked rows (models_gnn.py:261-265)."""
+    return nn.functional.l1_loss(output[target_mask], target[target_mask])
+
+
+class GNNModel(nn.Module):
+    """``forward(x, edge_index) -> [N, channels_out]`` (models_gnn.py:292-303)."""
+
+    def __init__(self, gnn_configs: GNNConfig) -> None:
+        super().__init__()
+        self.conv_layers = GCNConvLayers(gnn_configs)
+        self.activation = torch.nn.ReLU()
+
+    def prepare(self, edge_index: Tensor, num_nodes: int) -> GraphCSR:
+        """Prepare (or fetch) the normalised graph all six layers share."""
+        return default_cache().get(edge_index, num_nodes, None, add_self_loops=True,
+                                   improved=False, normalize=True)
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        if not isinstance(edge_index, GraphCSR):
+            edge_index = self.prepare(edge_index, x.size(-2))
+        return self.conv_layers(x, edge_index)

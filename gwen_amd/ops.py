@@ -1,0 +1,182 @@
+"""Tensor-level wrappers over the C ABI (include/gwen_hip.h) and the autograd Function of one layer.
+
+torch is used for device memory, the current HIP stream and autograd bookkeeping only; every
+arithmetic step of the layer runs in libgwen_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .graph import GraphCSR, _ptr, _stream
+
+
+def _require(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"gwen_amd: {name} must live on a HIP device (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"gwen_amd: {name} must be float32 (got {t.dtype})")
+
+
+def _rows2d(x: Tensor):
+    """[N,F] or [M,N,F] -> (members, N, F)."""
+    if x.dim() == 2:
+        return 1, x.size(0), x.size(1)
+    if x.dim() == 3:
+        return x.size(0), x.size(1), x.size(2)
+    raise ValueError(f"expected [N, F] or [members, N, F], got {tuple(x.shape)}")
+
+
+def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+              transposed: bool = False) -> Tensor:
+    """K2: out[i] = act(sum_s val[s] * h[col[s]] + bias) over the CSR (or its transpose)."""
+    _require(h, "h")
+    h = h.contiguous()
+    m, n, f = _rows2d(h)
+    if n != graph.num_nodes:
+        raise ValueError(f"h has {n} rows but the graph has {graph.num_nodes} nodes")
+    if transposed:
+        rowptr, col, val = graph.transposed()
+    else:
+        rowptr, col, val = graph.rowptr, graph.col, graph.val
+    if bias is not None:
+        _require(bias, "bias")
+        bias = bias.contiguous()
+    out = torch.empty_like(h)
+    dev = h.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_propagate_f32(
+            _ptr(rowptr), _ptr(col), _ptr(val), _ptr(h), _ptr(bias), _ptr(out), n, f, f, f, m,
+            n * f, n * f, int(relu), _stream(dev))
+    _lib.check(rc, "gwen_gcn_propagate_f32")
+    return out
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False) -> Tensor:
+    """K3: act(x @ weight^T + bias) on the fp32 MFMA; x [..., Fin], weight [Fout, Fin]."""
+    _require(x, "x")
+    _require(weight, "weight")
+    x = x.contiguous()
+    weight = weight.contiguous()
+    fin, fout = weight.size(1), weight.size(0)
+    if x.size(-1) != fin:
+        raise ValueError(f"x has {x.size(-1)} features but weight expects {fin}")
+    rows = math.prod(x.shape[:-1])
+    out = torch.empty(*x.shape[:-1], fout, dtype=torch.float32, device=x.device)
+    if bias is not None:
+        _require(bias, "bias")
+        bias = bias.contiguous()
+    dev = x.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_linear_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), rows, fin,
+                                            fout, fin, fout, int(relu), _stream(dev))
+    _lib.check(rc, "gwen_gcn_linear_f32")
+    return out
+
+
+def _grad_workspace(rows: int, fin: int, fout: int, dev) -> Tensor:
+    n = int(_lib.lib().gwen_gcn_grad_workspace_floats(rows, fin, fout))
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+def grad_weight(g: Tensor, x: Tensor) -> Tensor:
+    """grad_W [Fout, Fin] = g^T @ x over all leading rows."""
+    g = g.contiguous(); x = x.contiguous()
+    fout, fin = g.size(-1), x.size(-1)
+    rows = math.prod(g.shape[:-1])
+    out = torch.empty(fout, fin, dtype=torch.float32, device=g.device)
+    ws = _grad_workspace(rows, fin, fout, g.device)
+    with torch.cuda.device(g.device):
+        rc = _lib.lib().gwen_gcn_grad_weight_f32(_ptr(g), _ptr(x), _ptr(out), rows, fin, fout, fout,
+                                                 fin, _ptr(ws), _stream(g.device))
+    _lib.check(rc, "gwen_gcn_grad_weight_f32")
+    return out
+
+
+def grad_bias(g: Tensor) -> Tensor:
+    g = g.contiguous()
+    f = g.size(-1)
+    rows = math.prod(g.shape[:-1])
+    out = torch.empty(f, dtype=torch.float32, device=g.device)
+    ws = _grad_workspace(rows, f, 1, g.device)
+    with torch.cuda.device(g.device):
+        rc = _lib.lib().gwen_gcn_grad_bias_f32(_ptr(g), _ptr(out), rows, f, f, _ptr(ws),
+                                               _stream(g.device))
+    _lib.check(rc, "gwen_gcn_grad_bias_f32")
+    return out
+
+
+def relu_backward(y: Tensor, g: Tensor) -> Tensor:
+    y = y.contiguous(); g = g.contiguous()
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        rc = _lib.lib().gwen_relu_backward_f32(_ptr(y), _ptr(g), _ptr(out), g.numel(),
+                                               _stream(g.device))
+    _lib.check(rc, "gwen_relu_backward_f32")
+    return out
+
+
+class GCNLayerFunction(torch.autograd.Function):
+    """act(A~ (x W^T) + b): forward and backward entirely on the HIP kernels.
+
+    Order of the two linear maps is chosen per layer: transform-first (x W^T, then aggregate at width
+    Fout -- what PyG does) when Fout <= Fin, aggregate-first (A~ x at width Fin, then the projection
+    with the bias/ReLU epilogue) when Fin < Fout, so the gather always runs at the narrower width.
+    Both equal the reference's result up to fp32 rounding order (A~ is linear).
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], graph: GraphCSR,
+                relu: bool, order: str) -> Tensor:
+        fout, fin = weight.shape
+        if order == "auto":
+            order = "aggregate_first" if fin < fout else "transform_first"
+        if order == "transform_first":
+            h = linear(x, weight)
+            out = propagate(graph, h, bias, relu)
+            saved_in = x
+        elif order == "aggregate_first":
+            agg = propagate(graph, x)
+            out = linear(agg, weight, bias, relu)
+            saved_in = agg
+        else:
+            raise ValueError(f"unknown order {order!r}")
+        ctx.graph, ctx.relu, ctx.order, ctx.has_bias = graph, relu, order, bias is not None
+        ctx.save_for_backward(saved_in, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        saved_in, weight, out = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ctx.relu:
+            g = relu_backward(out, g)
+        gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gx = gw = None
+        if ctx.order == "transform_first":
+            gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
+            if ctx.needs_input_grad[1]:
+                gw = grad_weight(gh, saved_in)                     # gh^T x
+            if ctx.needs_input_grad[0]:
+                gx = linear(gh, weight.t().contiguous())           # gh W
+        else:
+            if ctx.needs_input_grad[1]:
+                gw = grad_weight(g, saved_in)                      # g^T (A~ x)
+            if ctx.needs_input_grad[0]:
+                gagg = linear(g, weight.t().contiguous())          # g W
+                gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)
+        return gx, gw, gb, None, None, None
+
+
+def gcn_layer(x: Tensor, weight: Tensor, bias: Optional[Tensor], graph: GraphCSR,
+              relu: bool = False, order: str = "auto") -> Tensor:
+    _require(x, "x")
+    _require(weight, "weight")
+    if x.device != weight.device or x.device != graph.device:
+        raise RuntimeError("x, weight and the graph must be on the same device")
+    return GCNLayerFunction.apply(x, weight, bias, graph, relu, order)

@@ -1,0 +1,113 @@
+/*
+ * gwen_hip.h -- C ABI of libgwen_hip.so: the MI355X (gfx950) implementation of GWEN's GCNConv
+ * hot path.  Plain pointers and sizes only; no torch types.  Every pointer is a DEVICE pointer
+ * unless the comment says "host".  All launchers are asynchronous on `stream` (a hipStream_t
+ * passed as void*), allocate nothing, synchronise nothing and keep no global state, so they can be
+ * captured into a hipGraph.
+ *
+ * The reference (MeteoSwiss/GWEN) has no C/FFI layer: its hot path is the Python call
+ * `GCNConv.__call__(x, edge_index)` into torch-geometric 2.3.1
+ * (/root/reference/src/gwen/models_gnn.py:19 import; :118-130,:172-184 constructors;
+ * :147-149,:204-206 calls).  Each entry point below names the piece of that call it replaces.
+ * The Python binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Return value: 0 on success; > 0 a hipError_t; < 0 one of the GWEN_E* codes.
+ */
+#ifndef GWEN_HIP_H
+#define GWEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GWEN_OK 0
+#define GWEN_EINVAL (-1)    /* bad size / null pointer / misaligned argument            */
+#define GWEN_ERANGE (-2)    /* N, E or a byte count does not fit the int32 CSR          */
+#define GWEN_ENOSPACE (-3)  /* workspace smaller than gwen_gcn_prep_workspace_bytes()   */
+
+typedef void *gwen_stream_t; /* hipStream_t */
+
+/* Library identification: "gwen_hip <semver> gfx950". */
+const char *gwen_hip_version(void);
+/* Text for a return code of any function below (hipGetErrorString for positive codes). */
+const char *gwen_hip_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  graph preparation == gcn_norm + add_remaining_self_loops, hoisted out of the layer
+ * (the reference recomputes it inside each of the 6 GCNConv calls of every forward:
+ *  /root/reference/src/gwen/models_gnn.py:147-149,:204-206; constructors pass cached=False).
+ *
+ * edge_index : int64 [2, E] row-major; row 0 = source j, row 1 = target i.
+ * edge_weight: fp32 [E] or NULL (unit weights; the reference never passes weights).
+ * Result: CSR by TARGET node with the N self-loops completed,
+ *   rowptr int32 [N+1], col int32 [cap], val fp32 [cap], eid int32 [cap], cap = E + N,
+ *   where row i holds its kept (non-loop) in-edges in ORIGINAL edge order followed by the
+ *   self-loop -- the order in which the reference's CPU scatter-add visits them --
+ *   col = source node, val = d^-1/2[src] * w * d^-1/2[dst] (or the raw w if !normalize),
+ *   eid = index of the edge in edge_index, -1 for a completed self-loop.
+ *   dis fp32 [N] = deg^-1/2 (inf -> 0).  rowptr[N] = number of stored entries E'.
+ * status: int32 [2]; status[0] is OR-ed with 1 if any node index is outside [0, N)
+ *   (such edges are dropped); status[1] = E'.  The caller zeroes nothing: prep does.
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_prep_workspace_bytes(int64_t N, int64_t E, size_t *bytes /* host */);
+int gwen_gcn_prep(const int64_t *edge_index, const float *edge_weight, int64_t N, int64_t E,
+                  int add_self_loops, float fill_value, int normalize, int32_t *rowptr,
+                  int32_t *col, float *val, int32_t *eid, float *dis, int32_t *status,
+                  void *workspace, size_t workspace_bytes, gwen_stream_t stream);
+
+/* Transposed structure (CSR by SOURCE) of a prepared graph, for the backward pass
+ * (grad_h = A~^T grad_out).  Same value array semantics; rows keep target order ascending.
+ * workspace: same size as for gwen_gcn_prep with E := rowptr[N] upper bound (E + N). */
+int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+                       int64_t cap, int32_t *t_rowptr, int32_t *t_col, float *t_val,
+                       void *workspace, size_t workspace_bytes, gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  fused propagate == MessagePassing.propagate (message w~ * x_j, aggregate add at target)
+ *     + bias add (GCNConv.forward) + torch.relu (/root/reference/src/gwen/models_gnn.py:147-149,
+ *     :204-205) in one pass:   out[m,i,:] = act( sum_s val[s] * h[m, col[s], :] + bias ).
+ * h   : fp32 [members, N, F] with row stride ldh (>= F) and member stride mstride_h (elements).
+ * out : fp32 [members, N, F] with row stride ldo and member stride mstride_o.  out != h.
+ * bias: fp32 [F] or NULL.  relu: 0/1.
+ * Terms are added sequentially in stored order with a rounded product per term (no FMA), so the
+ * result is bitwise reproducible and equals a sequential CPU scatter-add in edge order.
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_propagate_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                           const float *h, const float *bias, float *out, int64_t N, int64_t F,
+                           int64_t ldh, int64_t ldo, int64_t members, int64_t mstride_h,
+                           int64_t mstride_o, int relu, gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  dense projection == GCNConv.lin (PyG Linear(Fin, Fout, bias=False)):  h = x @ W^T.
+ * x [rows, Fin] (row stride ldx), W [Fout, Fin] contiguous (lin.weight), h [rows, Fout]
+ * (row stride ldh).  fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate: exact fp32 fmaf chain.
+ * Optional epilogue: + bias[Fout] (NULL = none), ReLU.
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows,
+                        int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldh, int relu,
+                        gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward pieces (autograd of the layer; the reference trains through it:
+ * /root/reference/src/gwen/models_gnn.py:372 loss.backward()).
+ *   grad_W[Fout,Fin] = g^T @ x   (g [rows,Fout], x [rows,Fin]); deterministic two-stage reduce.
+ *   grad_b[F]        = column sums of g.
+ *   relu mask        : g *= (y > 0).
+ * partial: fp32 workspace of gwen_gcn_grad_workspace_floats(rows, Fin, Fout) elements.
+ * ------------------------------------------------------------------------------------------- */
+int64_t gwen_gcn_grad_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout);
+int gwen_gcn_grad_weight_f32(const float *g, const float *x, float *grad_W, int64_t rows,
+                             int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx, float *partial,
+                             gwen_stream_t stream);
+int gwen_gcn_grad_bias_f32(const float *g, float *grad_b, int64_t rows, int64_t F, int64_t ldg,
+                           float *partial, gwen_stream_t stream);
+int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t count,
+                           gwen_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWEN_HIP_H */

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The built C-ABI library; building is cheap and idempotent."""
+    from gwen_amd import build as _b
+    _b.build()
+    from gwen_amd import _lib
+    return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def cref():
+    from oracle import gcn_ref
+    gcn_ref.build()
+    return gcn_ref

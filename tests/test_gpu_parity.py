@@ -1,0 +1,318 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerance: BASELINE.json north_star states 1e-4 relative fp32 (helpers.REL_TOL).  K1 and K2 are
+held to a stricter bar -- BIT-EXACT against the plain-C oracle -- because they reproduce the
+reference CPU path's visiting order and rounding (see DESIGN.md "Numerics").
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (REL_TOL, SEED, csr_from_oracle, graph_cases, make_params, random_multigraph,
+                     rel_err)
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ga(hip_lib):
+    import gwen_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return gwen_amd
+
+
+CASES = graph_cases()
+IDS = [c[0] for c in CASES]
+
+
+# ------------------------------------------------------------------------------------------------
+# K1: prepared CSR == oracle gcn_norm, entry for entry, bit for bit
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_prep_matches_oracle(ga, cref, case, weighted):
+    name, n, ei = case
+    ew = None
+    if weighted:
+        ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(SEED)) + 0.25
+    g = ga.prepare_graph(ei.to(DEV), n, None if ew is None else ew.to(DEV))
+    s, d, w = cref.norm(ei.numpy(), None if ew is None else ew.numpy(), n)
+    rowptr, col, val = csr_from_oracle(s, d, w, n)
+    nnz = g.nnz()
+    assert nnz == len(w)
+    np.testing.assert_array_equal(g.rowptr.cpu().numpy(), rowptr)
+    np.testing.assert_array_equal(g.col.cpu().numpy()[:nnz], col)
+    got = g.val.cpu().numpy()[:nnz]
+    assert got.tobytes() == val.astype(np.float32).tobytes(), f"{name}: weights differ in bits"
+
+
+@pytest.mark.parametrize("improved,loops,normalize", [(True, True, True), (False, False, True),
+                                                       (False, False, False)])
+def test_prep_options(ga, cref, improved, loops, normalize):
+    n, ei = 300, random_multigraph(300, 2000, self_loops=40, dup=100, isolate=7)
+    ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(1)) + 0.5
+    g = ga.prepare_graph(ei.to(DEV), n, ew.to(DEV), add_self_loops=loops, improved=improved,
+                         normalize=normalize)
+    if normalize:
+        s, d, w = cref.norm(ei.numpy(), ew.numpy(), n, add_self_loops=loops, fill=2.0 if improved else 1.0)
+    else:
+        s, d, w = ei[0].numpy(), ei[1].numpy(), ew.numpy()
+    rowptr, col, val = csr_from_oracle(s, d, w, n)
+    nnz = g.nnz()
+    np.testing.assert_array_equal(g.rowptr.cpu().numpy(), rowptr)
+    np.testing.assert_array_equal(g.col.cpu().numpy()[:nnz], col)
+    assert g.val.cpu().numpy()[:nnz].tobytes() == val.astype(np.float32).tobytes()
+
+
+def test_prep_rejects_bad_index(ga):
+    ei = torch.tensor([[0, 1, 5], [1, 0, 2]])
+    with pytest.raises(IndexError):
+        ga.prepare_graph(ei.to(DEV), 3)
+    with pytest.raises(TypeError):
+        ga.prepare_graph(ei.to(DEV).int(), 6)
+    with pytest.raises(ValueError):
+        ga.prepare_graph(torch.zeros(3, 4, dtype=torch.long, device=DEV), 6)
+    with pytest.raises(RuntimeError):
+        ga.prepare_graph(ei, 6)
+
+
+def test_transpose_matches_numpy(ga):
+    n, ei = 300, random_multigraph(300, 2000, self_loops=40, dup=100, isolate=7)
+    g = ga.prepare_graph(ei.to(DEV), n)
+    nnz = g.nnz()
+    rp, col, val = g.rowptr.cpu().numpy(), g.col.cpu().numpy()[:nnz], g.val.cpu().numpy()[:nnz]
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    order = np.argsort(col, kind="stable")
+    t_rp, t_col, t_val = (t.cpu().numpy() for t in g.transposed())
+    np.testing.assert_array_equal(t_rp, np.concatenate([[0], np.cumsum(np.bincount(col, minlength=n))]))
+    np.testing.assert_array_equal(t_col[:nnz], rows[order])
+    assert t_val[:nnz].tobytes() == val[order].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# K2: fused propagate, bit-exact against the sequential C oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 8, 12, 16, 24, 32, 64, 100, 128, 256, 260, 1000])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[7], CASES[3]], ids=[IDS[0], IDS[1], IDS[7], IDS[3]])
+def test_propagate_bit_exact(ga, cref, case, F):
+    from gwen_amd import ops
+    name, n, ei = case
+    gen = torch.Generator().manual_seed(SEED + F)
+    h = torch.randn(n, F, generator=gen)
+    b = torch.randn(F, generator=gen) * 0.1
+    g = ga.prepare_graph(ei.to(DEV), n)
+    s, d, w = cref.norm(ei.numpy(), None, n)
+    for bias, relu in ((None, False), (b, True)):
+        got = ops.propagate(g, h.to(DEV), None if bias is None else bias.to(DEV), relu).cpu().numpy()
+        ref = cref.propagate(s, d, w, h.numpy(), None if bias is None else bias.numpy(), relu)
+        assert got.tobytes() == ref.tobytes(), f"{name} F={F} relu={relu}: not bit-identical"
+
+
+def test_propagate_members_and_determinism(ga, cref):
+    from gwen_amd import ops
+    name, n, ei = CASES[0]
+    h = torch.randn(3, n, 64, generator=torch.Generator().manual_seed(SEED))
+    g = ga.prepare_graph(ei.to(DEV), n)
+    s, d, w = cref.norm(ei.numpy(), None, n)
+    a = ops.propagate(g, h.to(DEV)).cpu()
+    b = ops.propagate(g, h.to(DEV)).cpu()
+    assert torch.equal(a, b)
+    for m in range(3):
+        ref = cref.propagate(s, d, w, h[m].numpy())
+        assert a[m].numpy().tobytes() == ref.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# K3: fp32-MFMA projection
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,fin,fout", [(1002, 8, 8), (1002, 64, 64), (777, 64, 32), (130, 16, 32),
+                                            (1002, 256, 256), (125, 1000, 48), (33, 7, 5), (64, 3, 1),
+                                            (10, 0, 4), (129, 100, 260)])
+def test_linear(ga, cref, rows, fin, fout):
+    from gwen_amd import ops
+    gen = torch.Generator().manual_seed(SEED + rows + fin)
+    x = torch.randn(rows, fin, generator=gen)
+    w, b = make_params(fin, fout)
+    got = ops.linear(x.to(DEV), w.to(DEV)).cpu()
+    ref64 = x.double() @ w.double().t()
+    assert rel_err(got, ref64) <= 1e-5
+    chain = cref.linear(x.numpy(), w.numpy(), fma=True)           # k-ordered fmaf chain
+    assert got.numpy().tobytes() == chain.tobytes(), "fp32 MFMA is not the k-ordered fmaf chain"
+    got2 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True).cpu()
+    ref2 = torch.relu(torch.from_numpy(chain) + b)
+    assert torch.equal(got2, ref2)
+
+
+# ------------------------------------------------------------------------------------------------
+# one layer and the whole model against the torch oracle (the "reference PyTorch CPU path")
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
+@pytest.mark.parametrize("fin,fout", [(8, 8), (64, 32), (16, 32), (64, 64), (256, 256), (6, 10)])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[7]], ids=[IDS[0], IDS[1], IDS[7]])
+def test_layer_vs_oracle(ga, cref, case, fin, fout, order):
+    from oracle import gcn_oracle as O
+    name, n, ei = case
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(fin, fout)
+    conv = ga.GCNConv(fin, fout).to(DEV)
+    conv.order = order
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+        got = conv(x.to(DEV), ei.to(DEV)).cpu()
+    ref = O.gcn_conv(x, ei, w, b)
+    ref64 = torch.from_numpy(cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), f64=True))
+    assert rel_err(got, ref) <= REL_TOL
+    assert rel_err(got, ref64) <= REL_TOL
+    # the HIP path should be no further from fp64 truth than the fp32 oracle is (x4 slack)
+    assert rel_err(got, ref64) <= 4 * rel_err(ref, ref64) + 1e-6
+
+
+@pytest.mark.parametrize("C,H,nu", [(8, 16, 10), (8, 8, 10), (64, 64, 10), (20, 48, 4)])
+def test_model_vs_oracle(ga, C, H, nu):
+    from oracle import gcn_oracle as O
+    m = ga.geodesic_mesh(nu)
+    ei = torch.from_numpy(m.edge_index)
+    torch.manual_seed(SEED)
+    ref_model = O.OracleGNNModel(O.OracleGNNConfig(m.num_nodes, m.num_nodes, C, C, H))
+    with torch.no_grad():
+        for p in ref_model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    model = ga.GNNModel(ga.GNNConfig(m.num_nodes, m.num_nodes, C, C, H))
+    model.load_state_dict(ref_model.state_dict(), strict=True)
+    model = model.to(DEV).eval()
+    x = torch.randn(m.num_nodes, C)
+    with torch.no_grad():
+        got = model(x.to(DEV), ei.to(DEV)).cpu()
+        ref = ref_model(x, ei)
+        ref64 = ref_model.double()(x.double(), ei)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= REL_TOL
+    assert rel_err(got, ref64) <= REL_TOL
+
+
+def test_model_members_axis(ga):
+    """[members, N, C] input == the same members run one by one (shared prepared graph)."""
+    m = ga.geodesic_mesh(6)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(1, 1, 16, 16, 32)).to(DEV).eval()
+    x = torch.randn(4, m.num_nodes, 16, device=DEV)
+    with torch.no_grad():
+        batched = model(x, ei)
+        single = torch.stack([model(x[i], ei) for i in range(4)])
+    assert torch.equal(batched, single)
+
+
+# ------------------------------------------------------------------------------------------------
+# known-answer tests on the device
+# ------------------------------------------------------------------------------------------------
+def test_kat_complete_graph_is_mean(ga):
+    """On K_N (the reference's own graph, utils.py:176) every output row is mean_j(x_j W^T) + b."""
+    n, fin, fout = 125, 32, 16
+    ei = torch.from_numpy(ga.complete_graph(n)).to(DEV)
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(fin, fout)
+    conv = ga.GCNConv(fin, fout).to(DEV)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+        got = conv(x.to(DEV), ei).cpu().double()
+    want = (x.double() @ w.double().t()).mean(0, keepdim=True) + b.double()
+    assert rel_err(got, want.expand_as(got)) <= 1e-5
+
+
+def test_kat_path_and_cycle(ga):
+    fin = fout = 4
+    eye = torch.eye(4)
+    conv = ga.GCNConv(fin, fout).to(DEV)
+    with torch.no_grad():
+        conv.lin.weight.copy_(eye); conv.bias.zero_()
+    x = torch.randn(3, 4, generator=torch.Generator().manual_seed(SEED)).double()
+    ei = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])
+    got = conv(x.float().to(DEV), ei.to(DEV)).detach().cpu().double()
+    r6 = 1 / 6 ** 0.5
+    want = torch.stack([x[0] / 2 + x[1] * r6, x[0] * r6 + x[1] / 3 + x[2] * r6, x[1] * r6 + x[2] / 2])
+    assert rel_err(got, want) <= 1e-6
+    x = torch.randn(6, 4, generator=torch.Generator().manual_seed(SEED)).double()
+    ei = torch.tensor([[0, 1, 2, 3, 4, 5], [1, 2, 3, 4, 5, 0]])
+    got = conv(x.float().to(DEV), ei.to(DEV)).detach().cpu().double()
+    want = 0.5 * (x + torch.roll(x, 1, 0))
+    assert rel_err(got, want) <= 1e-6
+
+
+def test_properties_full_size(ga):
+    """BASELINE config-2 size (N=100 002, E=600 000, F=64): oracle comparison + linearity +
+    permutation equivariance + run-to-run determinism of the whole layer."""
+    from oracle import gcn_oracle as O
+    m = ga.geodesic_mesh(100)
+    n = m.num_nodes
+    ei = torch.from_numpy(m.edge_index)
+    gen = torch.Generator().manual_seed(SEED)
+    x = torch.randn(n, 64, generator=gen)
+    y = torch.randn(n, 64, generator=gen)
+    w, b = make_params(64, 64)
+    conv = ga.GCNConv(64, 64).to(DEV)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+        eid = ei.to(DEV)
+        fx = conv(x.to(DEV), eid)
+        assert torch.equal(fx, conv(x.to(DEV), eid))
+        ref = O.gcn_conv(x, ei, w, b)
+        assert rel_err(fx, ref) <= REL_TOL
+        fy = conv(y.to(DEV), eid)
+        fxy = conv((2 * x - y).to(DEV), eid)
+        lin = 2 * (fx - b.to(DEV)) - (fy - b.to(DEV)) + b.to(DEV)
+        assert rel_err(fxy, lin) <= 1e-5
+        perm = torch.randperm(n, generator=gen)
+        inv = torch.empty_like(perm); inv[perm] = torch.arange(n)
+        fp = conv(x[perm].to(DEV), inv[ei].to(DEV))          # node i -> position inv[i]
+        assert rel_err(fp, fx[perm.to(DEV)]) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# backward: gradients against torch autograd through the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[7]], ids=[IDS[0], IDS[1], IDS[7]])
+def test_layer_backward(ga, case, order):
+    from oracle import gcn_oracle as O
+    name, n, ei = case
+    fin, fout = 24, 40
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(fin, fout)
+    gout = torch.randn(n, fout, generator=torch.Generator().manual_seed(SEED + 1))
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    torch.relu(O.gcn_conv(xr, ei, wr, br)).backward(gout)
+    conv = ga.GCNConv(fin, fout).to(DEV)
+    conv.order = order
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+    xd = x.to(DEV).requires_grad_()
+    conv(xd, ei.to(DEV), relu=True).backward(gout.to(DEV))
+    assert rel_err(xd.grad, xr.grad) <= REL_TOL
+    assert rel_err(conv.lin.weight.grad, wr.grad) <= REL_TOL
+    assert rel_err(conv.bias.grad, br.grad) <= REL_TOL
+
+
+def test_model_training_step(ga):
+    """One optimiser step of the reference's loop shape (models_gnn.py:362-373) moves the loss."""
+    m = ga.geodesic_mesh(4)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(1, 1, 8, 8, 16)).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    x = torch.randn(m.num_nodes, 8, device=DEV)
+    mask = torch.zeros(m.num_nodes, dtype=torch.bool, device=DEV); mask[::3] = True
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = ga.loss_func(model(x, ei), x, mask)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    used = [p.grad is not None for n_, p in model.named_parameters()
+            if any(k in n_ for k in ("conv1.", "conv2.", "conv3.", "upconv3", "upconv4", "upconv5"))]
+    assert all(used)
