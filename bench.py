@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- GWEN GCNConv-stack hot path on MI355X: mesh edges/s (message+aggregate).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "c2"): synthetic ICON-CH1-scale geodesic mesh, nu = 100 ->
+N = 100 002 nodes, E = 600 000 directed edges; GNNModel(channels 64 -> hidden 64 -> 64), fp32,
+random-init weights (seed 23), 1 ensemble member per GPU.  One STEP = one GNNModel.forward of every
+local member = 6 GCNConv layers = 6 message+aggregate passes over the E mesh edges (plus their dense
+projections, bias and ReLU).  value = members * 6 * E * K / t  [edge passes per second, whole job].
+Inputs, weights and the prepared graph are resident in HBM before the timed region.  With N > 1
+members are sharded one per rank (weak scaling), there is no collective on the data path, and the
+single RCCL all-gather of the final states sits INSIDE the timed region, after the last step.
+
+Two extra objects ride on the JSON line (see DESIGN.md "Measurement"):
+  roofline     -- the dominant kernel (by summed time) of the timed region: algorithmic bytes per
+                  launch / its average duration from HIP events recorded around every one of its
+                  launches inside the timed region, against the 8 TB/s HBM peak.
+  cpu_baseline -- the torch oracle (kind "port": the reference's PyG is not installable) timed on
+                  this host's cores for the same workload, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--nu", type=int, default=100, help="mesh frequency: N = 10 nu^2 + 2")
+    p.add_argument("--channels", type=int, default=64)
+    p.add_argument("--hidden", type=int, default=64)
+    p.add_argument("--members-per-gpu", type=int, default=1)
+    p.add_argument("--reorder", default="morton", choices=["none", "morton"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    return p.parse_args()
+
+
+class KernelClock:
+    """HIP-event pairs around every launch of the instrumented kernels, on the launch stream
+    (torch's current stream is the stream handed to the C ABI)."""
+
+    def __init__(self):
+        self.pairs = {}       # key -> list of (start, stop)
+        self.enabled = False
+
+    def wrap(self, key, fn):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **k)
+            e.record()
+            self.pairs.setdefault(key(*a, **k), []).append((s, e))
+            return out
+        return timed
+
+    def summary(self):
+        out = {}
+        for k, prs in self.pairs.items():
+            ts = [s.elapsed_time(e) * 1e-3 for s, e in prs]      # seconds
+            out[k] = (len(ts), sum(ts))
+        return out
+
+
+def algorithmic_bytes(kind, n, e, fin, fout):
+    """B_alg = gathered source rows + self-loop row + output row + int32 col + fp32 weight
+    per stored entry + rowptr + (K3: x read, W read, h written)."""
+    if kind == "propagate":      # K2 at width F = fin = fout
+        f = fin
+        return 4 * f * (e + 2 * n) + 8 * e + 8 * n
+    if kind == "linear":         # K3
+        return 4 * n * (fin + fout) + 4 * fin * fout
+    raise KeyError(kind)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import gwen_amd
+    from gwen_amd import ensemble, ops
+
+    # ---- synthetic inputs, resident in HBM ------------------------------------------------------
+    mesh = gwen_amd.geodesic_mesh(args.nu, reorder=None if args.reorder == "none" else args.reorder)
+    n, e = mesh.num_nodes, mesh.num_edges
+    c, h = args.channels, args.hidden
+    m_local = args.members_per_gpu
+    members = m_local * world
+    lo, hi = ensemble.member_range(members, rank, world)
+    torch.manual_seed(23)                                            # config.json:14
+    model = gwen_amd.GNNModel(gwen_amd.GNNConfig(n, n, c, c, h))
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.dim() == 1:
+                p_.normal_(0.0, 0.1)                                 # exercise the bias path
+    model = model.to(dev).eval()
+    x = torch.stack([torch.randn(n, c, generator=torch.Generator().manual_seed(23 + m))
+                     for m in range(lo, hi)]).to(dev)
+    if m_local == 1:
+        x = x[0]
+    edge_index = torch.from_numpy(mesh.edge_index).to(dev)
+    graph = model.prepare(edge_index, n)                              # K1, once, outside the timed region
+    layers = 6
+    widths = [(c, h), (h, h // 2), (h // 2, h // 4), (h // 4, h // 2), (h // 2, h), (h, c)]
+
+    # ---- per-kernel clocks --------------------------------------------------------------------
+    clock = KernelClock()
+    ops.propagate = clock.wrap(lambda g, t, *a, **k: ("propagate", t.size(-1), t.size(-1)), ops.propagate)
+    ops.linear = clock.wrap(lambda t, w, *a, **k: ("linear", w.size(1), w.size(0)), ops.linear)
+
+    def step():
+        with torch.no_grad():
+            return model(x, graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+
+    # ---- timed region ---------------------------------------------------------------------------
+    clock.enabled = True
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    final = out if out.dim() == 3 else out.unsqueeze(0)
+    gathered = ensemble.gather_members(final, members) if world > 1 else final
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    clock.enabled = False
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    assert gathered.shape[0] == members and torch.isfinite(gathered).all()
+
+    # ---- roofline of the dominant kernel (events recorded inside the timed region) ---------------
+    summ = clock.summary()
+    dom_key = max(summ, key=lambda k: summ[k][1])
+    launches, total_s = summ[dom_key]
+    kind, fin, fout = dom_key
+    b_alg = algorithmic_bytes(kind, n, e, fin, fout) * m_local
+    avg_s = total_s / launches
+    achieved = b_alg / avg_s / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": round(avg_s * 1e6, 2),
+        "launches": launches,
+        "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())},
+    }
+
+    value = members * layers * e * args.steps / elapsed
+    line = {
+        "metric": "mesh edges/s (message+aggregate)", "value": value, "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c2: geodesic mesh nu={args.nu} N={n} E={e}, GNNModel forward "
+                               f"C={c} H={h} (6 GCNConv layers), {m_local} member/GPU",
+                   "nodes": n, "edges": e, "channels": c, "hidden": h, "layers": layers,
+                   "members": members, "node_order": args.reorder,
+                   "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
+        "members_per_s": members * args.steps / elapsed,
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the torch oracle on this host's cores (rank 0, N = 1 only) ----------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import gcn_oracle as O
+        ref = O.OracleGNNModel(O.OracleGNNConfig(n, n, c, c, h))
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
+        xc = (x if x.dim() == 2 else x[0]).cpu()
+        eic = torch.from_numpy(mesh.edge_index)
+        cores = torch.get_num_threads()
+        with torch.no_grad():
+            tw = time.perf_counter(); yc = ref(xc, eic); one = time.perf_counter() - tw   # warm-up
+            reps = max(1, min(20, int(args.cpu_seconds / max(one, 1e-3))))
+            ts = []
+            for _ in range(reps):
+                tw = time.perf_counter(); yc = ref(xc, eic); ts.append(time.perf_counter() - tw)
+        med = sorted(ts)[len(ts) // 2]
+        got = (out if out.dim() == 2 else out[0]).cpu()
+        err = float((got - yc).abs().max() / yc.abs().max())
+        line["cpu_baseline"] = {
+            "value": layers * e / med, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full GNNModel.forward passes of the same c2 workload (1 member), median "
+                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU, oracle/gcn_oracle.py",
+            "gpu_vs_oracle_rel_err": err,
+        }
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+"""Host-side logic on CPU: mesh generator, module surface / state_dict, pickling, error behaviour,
+graph cache and ensemble partitioning."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import gwen_amd
+from gwen_amd import ensemble, graph as G
+from helpers import SEED
+from oracle import gcn_oracle as O
+
+
+@pytest.mark.parametrize("nu", [1, 2, 3, 7, 10])
+def test_geodesic_mesh_counts_and_conventions(nu):
+    m = gwen_amd.geodesic_mesh(nu)
+    n, e = 10 * nu * nu + 2, 60 * nu * nu
+    assert m.num_nodes == n and m.num_edges == e and len(m.faces) == 20 * nu * nu
+    ei = m.edge_index
+    assert ei.dtype == np.int64 and ei.shape == (2, e)
+    assert (ei[0] != ei[1]).all()                                   # no self-loops
+    key = ei[0] * n + ei[1]
+    assert (np.diff(key) > 0).all()                                 # sorted by (row, col), no duplicates
+    rev = np.sort(ei[1] * n + ei[0])
+    assert np.array_equal(rev, key)                                 # both directions present
+    deg = np.bincount(ei[1], minlength=n)
+    assert (deg == 5).sum() == 12 and (deg == 6).sum() == n - 12 if nu > 1 else (deg == 5).all()
+    assert np.allclose(np.linalg.norm(m.pos, axis=1), 1.0)
+    # Euler: V - E/2 + F = 2
+    assert n - e // 2 + len(m.faces) == 2
+
+
+def test_c2_mesh_size_and_morton_relabelling_is_isomorphic():
+    m = gwen_amd.geodesic_mesh(100)
+    assert (m.num_nodes, m.num_edges) == (100002, 600000)
+    a, b = gwen_amd.geodesic_mesh(6), gwen_amd.geodesic_mesh(6, reorder="morton")
+    inv = np.empty_like(b.perm); inv[b.perm] = np.arange(len(inv))
+    ea = inv[a.edge_index]
+    ka = np.sort(ea[0] * a.num_nodes + ea[1]); kb = b.edge_index[0] * b.num_nodes + b.edge_index[1]
+    assert np.array_equal(ka, kb)
+    assert np.allclose(a.pos[b.perm], b.pos)
+
+
+def test_complete_graph_matches_reference_producer_conventions():
+    ei = gwen_amd.complete_graph(5)       # erdos_renyi_graph(5, 1): utils.py:176
+    assert ei.shape == (2, 20) and (ei[0] != ei[1]).all()
+    assert (np.diff(ei[0] * 5 + ei[1]) > 0).all()
+
+
+def test_state_dict_is_appendix_b():
+    c, h = 12, 32
+    m = gwen_amd.GNNModel(gwen_amd.GNNConfig(9, 9, c, c + 1, h))
+    sd = m.state_dict()
+    want = {}
+    dims = {"down_conv_layers.conv1": (h, c), "down_conv_layers.conv2": (h // 2, h),
+            "down_conv_layers.conv3": (h // 4, h // 2), "down_conv_layers.conv4": (h // 8, h // 4),
+            "down_conv_layers.conv5": (h // 16, h // 8), "up_conv_layers.upconv1": (h // 8, h // 16),
+            "up_conv_layers.upconv2": (h // 4, h // 8), "up_conv_layers.upconv3": (h // 2, h // 4),
+            "up_conv_layers.upconv4": (h, h // 2), "up_conv_layers.upconv5": (c + 1, h)}
+    for k, (o, i) in dims.items():
+        want[f"conv_layers.{k}.bias"] = (o,)
+        want[f"conv_layers.{k}.lin.weight"] = (o, i)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    assert list(sd)[:2] == ["conv_layers.down_conv_layers.conv1.bias",
+                            "conv_layers.down_conv_layers.conv1.lin.weight"]   # bias first, as PyG
+
+
+def test_state_dict_round_trip_with_oracle_model_strict():
+    cfg = (7, 7, 8, 8, 16)
+    torch.manual_seed(SEED)
+    ref = O.OracleGNNModel(O.OracleGNNConfig(*cfg))
+    mine = gwen_amd.GNNModel(gwen_amd.GNNConfig(*cfg))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    ref2 = O.OracleGNNModel(O.OracleGNNConfig(*cfg))
+    ref2.load_state_dict(mine.state_dict(), strict=True)
+    for a, b in zip(ref.state_dict().values(), ref2.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+def test_initialisation_glorot_and_zero_bias():
+    torch.manual_seed(SEED)
+    conv = gwen_amd.GCNConv(300, 200)
+    a = (6.0 / 500) ** 0.5
+    w = conv.lin.weight
+    assert float(w.detach().abs().max()) <= a and float(w.detach().abs().max()) > 0.95 * a
+    assert abs(float(w.detach().mean())) < 0.01 * a * 10 and torch.count_nonzero(conv.bias) == 0
+    assert gwen_amd.GCNConv(4, 4, bias=False).bias is None
+    assert list(gwen_amd.GCNConv(4, 4, bias=False).state_dict()) == ["lin.weight"]
+    with pytest.raises(TypeError):
+        gwen_amd.GCNConv(4, 4, flow="target_to_source")
+
+
+def test_hidden_feats_8_gives_zero_width_layers_like_the_reference():
+    # BASELINE config c1 uses 8 hidden channels: conv5 = GCNConv(1, 0), upconv1 = GCNConv(0, 1)
+    m = gwen_amd.GNNModel(gwen_amd.GNNConfig(1, 1, 8, 8, 8))
+    assert tuple(m.conv_layers.down_conv_layers.conv5.lin.weight.shape) == (0, 1)
+    assert tuple(m.conv_layers.up_conv_layers.upconv1.lin.weight.shape) == (1, 0)
+
+
+def test_module_is_picklable_and_drops_device_state():
+    m = gwen_amd.GNNModel(gwen_amd.GNNConfig(3, 3, 8, 8, 16))
+    m.conv_layers.down_conv_layers.conv1._cached_graph = object()
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2.conv_layers.down_conv_layers.conv1._cached_graph is None
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+    cfg = pickle.loads(pickle.dumps(gwen_amd.GNNConfig(3, 3, 8, 8, 16)))
+    assert cfg.hidden_feats == 16
+
+
+def test_cpu_tensors_raise_runtime_error_not_fallback():
+    m = gwen_amd.GNNModel(gwen_amd.GNNConfig(3, 3, 8, 8, 16))
+    x, ei = torch.randn(3, 8), torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, ei)
+    conv = gwen_amd.GCNConv(8, 4)
+    with pytest.raises(RuntimeError):
+        conv(x, ei)
+    with pytest.raises(ValueError):
+        conv(torch.randn(3, 5), ei)
+    with pytest.raises(ValueError):
+        conv(torch.randn(8), ei)
+    with pytest.raises(TypeError):
+        conv(np.zeros((3, 8)), ei)
+
+
+def test_graph_cache_keys_on_tensor_identity(monkeypatch):
+    calls = []
+    monkeypatch.setattr(G, "prepare_graph", lambda ei, n, ew=None, **kw: calls.append((id(ei), n, kw)) or object())
+    cache = G.GraphCache(capacity=2)
+    opts = dict(add_self_loops=True, improved=False, normalize=True)
+    a = torch.tensor([[0, 1], [1, 0]])
+    g1 = cache.get(a, 2, None, **opts)
+    assert cache.get(a, 2, None, **opts) is g1 and len(calls) == 1        # same object: hit
+    b = a.clone()
+    assert cache.get(b, 2, None, **opts) is not g1 and len(calls) == 2    # equal content, new object: miss
+    a[0, 0] = 1                                                           # in-place edit bumps _version
+    assert cache.get(a, 2, None, **opts) is not g1 and len(calls) == 3
+    assert cache.get(a, 3, None, **opts) is not None and len(calls) == 4  # other num_nodes
+    w = torch.ones(2)
+    cache.get(a, 2, w, **opts); cache.get(a, 2, w, **opts)
+    assert len(calls) == 5
+    assert len(cache._d) <= 2                                             # LRU bound
+    # a dead tensor whose id is reused must not hit
+    c = torch.tensor([[0], [1]]); cache.get(c, 2, None, **opts); key_id = id(c); del c
+    n_before = len(calls)
+    d = torch.tensor([[1], [0]])
+    cache.get(d, 2, None, **opts)
+    assert len(calls) == n_before + 1
+
+
+def test_member_range_partitions_every_member_once():
+    for members in (0, 1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [ensemble.member_range(members, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == members
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == ensemble.member_counts(members, world)
+    with pytest.raises(ValueError):
+        ensemble.member_range(4, 4, 4)
+
+
+def test_gather_members_single_process_is_identity():
+    x = torch.randn(3, 5, 2)
+    assert ensemble.gather_members(x, 3) is x
+    with pytest.raises(ValueError):
+        ensemble.gather_members(x, 4)
+    out = ensemble.ensemble_rollout(lambda s: s + 1, x, 4, 3)
+    assert torch.allclose(out, x + 4)
