@@ -16,8 +16,8 @@ single RCCL all-gather of the final states sits INSIDE the timed region, after t
 
 Two extra objects ride on the JSON line (see DESIGN.md "Measurement"):
   roofline     -- the dominant kernel (by summed time) of the timed region: algorithmic bytes per
-                  launch / its average duration from HIP events recorded around every one of its
-                  launches inside the timed region, against the 8 TB/s HBM peak.
+                  launch / its average duration from hipEvents the launcher records around every
+                  kernel launch (on the launch stream) inside the timed region, against 8 TB/s.
   cpu_baseline -- the torch oracle (kind "port": the reference's PyG is not installable) timed on
                   this host's cores for the same workload, rank 0, N = 1 only.
 """
@@ -49,37 +49,11 @@ def parse():
     p.add_argument("--hidden", type=int, default=64)
     p.add_argument("--members-per-gpu", type=int, default=1)
     p.add_argument("--reorder", default="morton", choices=["none", "morton"])
+    p.add_argument("--order", default="auto", choices=["auto", "unfused"],
+                   help="auto: K4 fused layer where the widths allow; unfused: K3 + K2 per layer")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return p.parse_args()
-
-
-class KernelClock:
-    """HIP-event pairs around every launch of the instrumented kernels, on the launch stream
-    (torch's current stream is the stream handed to the C ABI)."""
-
-    def __init__(self):
-        self.pairs = {}       # key -> list of (start, stop)
-        self.enabled = False
-
-    def wrap(self, key, fn):
-        def timed(*a, **k):
-            if not self.enabled:
-                return fn(*a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = fn(*a, **k)
-            e.record()
-            self.pairs.setdefault(key(*a, **k), []).append((s, e))
-            return out
-        return timed
-
-    def summary(self):
-        out = {}
-        for k, prs in self.pairs.items():
-            ts = [s.elapsed_time(e) * 1e-3 for s, e in prs]      # seconds
-            out[k] = (len(ts), sum(ts))
-        return out
 
 
 def algorithmic_bytes(kind, n, e, fin, fout):
@@ -88,8 +62,10 @@ def algorithmic_bytes(kind, n, e, fin, fout):
     if kind == "propagate":      # K2 at width F = fin = fout
         f = fin
         return 4 * f * (e + 2 * n) + 8 * e + 8 * n
-    if kind == "linear":         # K3
+    if kind == "linear":         # K3: x read, h written, W read
         return 4 * n * (fin + fout) + 4 * fin * fout
+    if kind == "layer":          # K4: gather at fin (E edges + self-loop), store at fout, indices, W
+        return 4 * fin * (e + n) + 4 * fout * n + 8 * e + 8 * n + 4 * fin * fout
     raise KeyError(kind)
 
 
@@ -109,7 +85,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import gwen_amd
-    from gwen_amd import ensemble, ops
+    from gwen_amd import ensemble
 
     # ---- synthetic inputs, resident in HBM ------------------------------------------------------
     mesh = gwen_amd.geodesic_mesh(args.nu, reorder=None if args.reorder == "none" else args.reorder)
@@ -125,6 +101,10 @@ def main():
             if p_.dim() == 1:
                 p_.normal_(0.0, 0.1)                                 # exercise the bias path
     model = model.to(dev).eval()
+    if args.order == "unfused":
+        for mod in model.modules():
+            if isinstance(mod, gwen_amd.GCNConv):
+                mod.order = "aggregate_first" if mod.in_channels < mod.out_channels else "transform_first"
     x = torch.stack([torch.randn(n, c, generator=torch.Generator().manual_seed(23 + m))
                      for m in range(lo, hi)]).to(dev)
     if m_local == 1:
@@ -134,45 +114,49 @@ def main():
     layers = 6
     widths = [(c, h), (h, h // 2), (h // 2, h // 4), (h // 4, h // 2), (h // 2, h), (h, c)]
 
-    # ---- per-kernel clocks --------------------------------------------------------------------
-    clock = KernelClock()
-    ops.propagate = clock.wrap(lambda g, t, *a, **k: ("propagate", t.size(-1), t.size(-1)), ops.propagate)
-    ops.linear = clock.wrap(lambda t, w, *a, **k: ("linear", w.size(1), w.size(0)), ops.linear)
+    # ---- the whole stack behind one C call; hipEvents around every kernel launch ----------------
+    plan = gwen_amd.StackForward(model.stack(), graph)
+    out = plan.run(x)                                                 # allocates scratch + output
+    n_sets = min(args.steps, 256)                                     # event sets (one per timed step,
+    stride = (args.steps + n_sets - 1) // n_sets                      #  every stride-th step beyond 256)
+    ev_sets = [gwen_amd.KernelEvents(2 * layers) for _ in range(n_sets)]
 
-    def step():
-        with torch.no_grad():
-            return model(x, graph)
+    def step(ev=None):
+        return plan.run(x, out=out, events=ev)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     for _ in range(args.warmup):
-        out = step()
+        step()
     torch.cuda.synchronize()
     barrier()
 
     # ---- timed region ---------------------------------------------------------------------------
-    clock.enabled = True
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        step(ev_sets[i // stride] if i % stride == 0 else None)
     final = out if out.dim() == 3 else out.unsqueeze(0)
     gathered = ensemble.gather_members(final, members) if world > 1 else final
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    clock.enabled = False
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     assert gathered.shape[0] == members and torch.isfinite(gathered).all()
 
+    summ = {}
+    for evs in ev_sets:
+        for kind, layer, fin, fout, sec in evs.durations():
+            cnt, tot = summ.get((kind, fin, fout), (0, 0.0))
+            summ[(kind, fin, fout)] = (cnt + 1, tot + sec)
+
     # ---- roofline of the dominant kernel (events recorded inside the timed region) ---------------
-    summ = clock.summary()
     dom_key = max(summ, key=lambda k: summ[k][1])
     launches, total_s = summ[dom_key]
     kind, fin, fout = dom_key
@@ -196,7 +180,7 @@ def main():
         "config": {"workload": f"c2: geodesic mesh nu={args.nu} N={n} E={e}, GNNModel forward "
                                f"C={c} H={h} (6 GCNConv layers), {m_local} member/GPU",
                    "nodes": n, "edges": e, "channels": c, "hidden": h, "layers": layers,
-                   "members": members, "node_order": args.reorder,
+                   "members": members, "node_order": args.reorder, "kernel_order": args.order,
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
         "members_per_s": members * args.steps / elapsed,
         "roofline": roofline,

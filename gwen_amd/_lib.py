@@ -20,6 +20,23 @@ _lock = threading.Lock()
 
 _vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
+
+
+class LayerDesc(C.Structure):
+    """gwen_layer_desc (include/gwen_hip.h)."""
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("fin", C.c_int32), ("fout", C.c_int32),
+                ("relu", C.c_int32), ("order", C.c_int32)]
+
+
+class LaunchInfo(C.Structure):
+    """gwen_launch_info (include/gwen_hip.h)."""
+    _fields_ = [("kind", C.c_int32), ("layer", C.c_int32), ("fin", C.c_int32), ("fout", C.c_int32)]
+
+
+ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED = -1, 0, 1, 2
+KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER = 2, 3, 4
+KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer"}
+
 # name -> (restype, argtypes); mirrors include/gwen_hip.h one to one
 SIGNATURES = {
     "gwen_hip_version": (C.c_char_p, []),
@@ -31,6 +48,17 @@ SIGNATURES = {
     "gwen_gcn_propagate_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                       _i64, _i64, _int, _vp]),
     "gwen_gcn_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
+    "gwen_gcn_layer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                  _i64, _i64, _i64, _int, _vp]),
+    "gwen_gcn_layer_supported": (_int, [_i64, _i64]),
+    "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
+    "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
+                                    _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
+                                    C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]),
+    "gwen_event_create": (_int, [C.POINTER(C.c_void_p)]),
+    "gwen_event_destroy": (_int, [_vp]),
+    "gwen_event_synchronize": (_int, [_vp]),
+    "gwen_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "gwen_gcn_grad_workspace_floats": (_i64, [_i64, _i64, _i64]),
     "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

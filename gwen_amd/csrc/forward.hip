@@ -1,0 +1,146 @@
+// Whole-stack forward: every kernel of GNNModel.forward issued back to back from one host call.
+//
+// Replaces the host side of /root/reference/src/gwen/models_gnn.py:292-303 -> :241-258 ->
+// :135-157 / :189-212 (six GCNConv.__call__ + five torch.relu, ~15 eager launches per layer with
+// the normalisation recomputed each time): here one call enqueues 6..12 launches on one stream
+// with no allocation and no synchronisation, so it is hipGraph-capturable and the host stays ahead
+// of the device.  Optional hipEvents bracket every launch for in-situ kernel timing.
+#include "common.h"
+
+namespace {
+
+struct Plan {
+  int64_t ping, pong, tmp;   // element offsets into scratch
+  int64_t total;
+};
+
+inline int resolve_order(const gwen_layer_desc &L) {
+  if (L.order == GWEN_ORDER_AUTO) {
+    if (gwen_gcn_layer_supported(L.fin, L.fout)) return GWEN_ORDER_FUSED;
+    return L.fin < L.fout ? GWEN_ORDER_AGGREGATE_FIRST : GWEN_ORDER_TRANSFORM_FIRST;
+  }
+  return L.order;
+}
+
+inline int64_t round4(int64_t v) { return (v + 3) / 4 * 4; }
+
+int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t n, Plan *P) {
+  int64_t out_w = 0, tmp_w = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const gwen_layer_desc &L = layers[i];
+    if (L.fin < 0 || L.fout < 0) return GWEN_EINVAL;
+    if (i > 0 && layers[i - 1].fout != L.fin) return GWEN_EINVAL;
+    const int o = resolve_order(L);
+    if (o == GWEN_ORDER_FUSED && !gwen_gcn_layer_supported(L.fin, L.fout)) return GWEN_EINVAL;
+    if (i + 1 < n && L.fout > out_w) out_w = L.fout;
+    if (o == GWEN_ORDER_TRANSFORM_FIRST && L.fout > tmp_w) tmp_w = L.fout;
+    if (o == GWEN_ORDER_AGGREGATE_FIRST && L.fin > tmp_w) tmp_w = L.fin;
+  }
+  const int64_t rows = members * N;
+  P->ping = 0;
+  P->pong = round4(rows * out_w);
+  P->tmp = P->pong + round4(rows * out_w);
+  P->total = P->tmp + round4(rows * tmp_w) + 4;
+  return GWEN_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members,
+                                                   const gwen_layer_desc *layers, int32_t n_layers) {
+  Plan P;
+  if (N < 0 || members < 0 || n_layers < 0 || (n_layers > 0 && !layers)) return GWEN_EINVAL;
+  if (make_plan(N, members, layers, n_layers, &P) != GWEN_OK) return GWEN_EINVAL;
+  return P.total;
+}
+
+extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                    int64_t N, const gwen_layer_desc *layers, int32_t n_layers,
+                                    const float *x, float *out, float *scratch,
+                                    int64_t scratch_floats, int64_t members, gwen_stream_t stream,
+                                    void **events, gwen_launch_info *info, int32_t max_launches,
+                                    int32_t *n_launches) {
+  if (N < 0 || members < 0 || n_layers <= 0 || !layers) return GWEN_EINVAL;
+  Plan P;
+  int rc = make_plan(N, members, layers, n_layers, &P);
+  if (rc != GWEN_OK) return rc;
+  if (scratch_floats < P.total || (P.total > 4 && !scratch)) return GWEN_ENOSPACE;
+  if (scratch && !gwen_aligned(scratch, 16)) return GWEN_EINVAL;
+  if ((events || info) && max_launches < 2 * n_layers) return GWEN_EINVAL;
+  hipStream_t st = gwen_stream(stream);
+  const int64_t rows = members * N;
+  float *buf[2] = {scratch + P.ping, scratch + P.pong};
+  float *tmp = scratch + P.tmp;
+  int32_t nl = 0;
+
+  auto before = [&](int kind, int layer, int fin, int fout) -> int {
+    if (info) info[nl] = gwen_launch_info{kind, layer, fin, fout};
+    if (events) GWEN_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(events[2 * nl]), st));
+    return GWEN_OK;
+  };
+  auto after = [&]() -> int {
+    if (events) GWEN_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(events[2 * nl + 1]), st));
+    ++nl;
+    return GWEN_OK;
+  };
+#define GWEN_TRY(expr) do { int _r = (expr); if (_r != GWEN_OK) return _r; } while (0)
+
+  const float *cur = x;
+  for (int32_t i = 0; i < n_layers; ++i) {
+    const gwen_layer_desc &L = layers[i];
+    float *dst = (i + 1 == n_layers) ? out : buf[i & 1];
+    const int o = resolve_order(L);
+    const int64_t fi = L.fin, fo = L.fout;
+    if (o == GWEN_ORDER_FUSED) {
+      GWEN_TRY(before(GWEN_KIND_LAYER, i, fi, fo));
+      GWEN_TRY(gwen_gcn_layer_f32(rowptr, col, val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
+                                  members, N * fi, N * fo, L.relu, stream));
+      GWEN_TRY(after());
+    } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
+      GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
+      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, stream));
+      GWEN_TRY(after());
+      GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fo, fo));
+      GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, tmp, L.bias, dst, N, fo, fo, fo, members,
+                                      N * fo, N * fo, L.relu, stream));
+      GWEN_TRY(after());
+    } else if (o == GWEN_ORDER_AGGREGATE_FIRST) {
+      GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fi, fi));
+      GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, cur, nullptr, tmp, N, fi, fi, fi, members,
+                                      N * fi, N * fi, 0, stream));
+      GWEN_TRY(after());
+      GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
+      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, stream));
+      GWEN_TRY(after());
+    } else {
+      return GWEN_EINVAL;
+    }
+    cur = dst;
+  }
+#undef GWEN_TRY
+  if (n_launches) *n_launches = nl;
+  return GWEN_OK;
+}
+
+extern "C" int gwen_event_create(void **event) {
+  if (!event) return GWEN_EINVAL;
+  hipEvent_t e;
+  GWEN_HIP_CHECK(hipEventCreate(&e));
+  *event = e;
+  return GWEN_OK;
+}
+extern "C" int gwen_event_destroy(void *event) {
+  if (!event) return GWEN_OK;
+  GWEN_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return GWEN_OK;
+}
+extern "C" int gwen_event_synchronize(void *event) {
+  if (!event) return GWEN_EINVAL;
+  GWEN_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return GWEN_OK;
+}
+extern "C" int gwen_event_elapsed_ms(void *start, void *stop, float *ms) {
+  if (!start || !stop || !ms) return GWEN_EINVAL;
+  GWEN_HIP_CHECK(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return GWEN_OK;
+}

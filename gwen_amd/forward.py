@@ -1,0 +1,131 @@
+"""Host side of the whole-stack launcher ``gwen_gnn_forward_f32`` (include/gwen_hip.h).
+
+One C call enqueues every kernel of ``GNNModel.forward`` (/root/reference/src/gwen/models_gnn.py:
+292-303) on torch's current HIP stream: no per-layer Python, no allocation inside, hipGraph-capturable.
+Used for inference (``torch.no_grad``); training goes through the per-layer autograd Function.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .graph import GraphCSR, _ptr, _stream
+
+_ORDERS = {"auto": _lib.ORDER_AUTO, "transform_first": _lib.ORDER_TRANSFORM_FIRST,
+           "aggregate_first": _lib.ORDER_AGGREGATE_FIRST, "fused": _lib.ORDER_FUSED}
+
+
+class KernelEvents:
+    """hipEvent pairs recorded by the launcher around each kernel launch of one forward."""
+
+    def __init__(self, max_launches: int):
+        self.max_launches = max_launches
+        self._ev = (C.c_void_p * (2 * max_launches))()
+        self.info = (_lib.LaunchInfo * max_launches)()
+        self.n = C.c_int32(0)
+        L = _lib.lib()
+        for i in range(2 * max_launches):
+            h = C.c_void_p()
+            _lib.check(L.gwen_event_create(C.byref(h)), "gwen_event_create")
+            self._ev[i] = h
+
+    def durations(self) -> List[Tuple[str, int, int, int, float]]:
+        """[(kind, layer, fin, fout, seconds)] of the last forward (synchronises on the last event)."""
+        L = _lib.lib()
+        n = self.n.value
+        if n == 0:
+            return []
+        _lib.check(L.gwen_event_synchronize(self._ev[2 * n - 1]), "gwen_event_synchronize")
+        out = []
+        ms = C.c_float(0)
+        for i in range(n):
+            _lib.check(L.gwen_event_elapsed_ms(self._ev[2 * i], self._ev[2 * i + 1], C.byref(ms)),
+                       "gwen_event_elapsed_ms")
+            it = self.info[i]
+            out.append((_lib.KIND_NAMES.get(it.kind, str(it.kind)), it.layer, it.fin, it.fout,
+                        ms.value * 1e-3))
+        return out
+
+    def close(self) -> None:
+        L = _lib.lib()
+        for i in range(2 * self.max_launches):
+            if self._ev[i]:
+                L.gwen_event_destroy(self._ev[i])
+                self._ev[i] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StackForward:
+    """A stack of GCN layers bound to one prepared graph: ``run(x)`` is one C call."""
+
+    def __init__(self, layers: Sequence[Tuple[Tensor, Optional[Tensor], bool, str]], graph: GraphCSR):
+        if not layers:
+            raise ValueError("need at least one layer")
+        self.graph = graph
+        self._keep = []                      # tensors whose pointers sit in the descriptor array
+        self.desc = (_lib.LayerDesc * len(layers))()
+        for i, (w, b, relu, order) in enumerate(layers):
+            if not w.is_cuda or w.dtype != torch.float32:
+                raise RuntimeError("layer weights must be float32 on a HIP device (no CPU fallback)")
+            w = w.detach().contiguous()
+            b = None if b is None else b.detach().contiguous()
+            self._keep += [w, b]
+            d = self.desc[i]
+            d.W, d.bias = w.data_ptr(), (0 if b is None else b.data_ptr())
+            d.fout, d.fin = w.size(0), w.size(1)
+            d.relu, d.order = int(relu), _ORDERS[order]
+        self.fin, self.fout = self.desc[0].fin, self.desc[len(layers) - 1].fout
+        self._scratch: Optional[Tensor] = None
+        self._scratch_key = None
+
+    def _scratch_for(self, members: int, dev) -> Tensor:
+        key = (members, dev)
+        if self._scratch_key != key:
+            n = int(_lib.lib().gwen_gnn_forward_scratch_floats(self.graph.num_nodes, members, self.desc,
+                                                               len(self.desc)))
+            if n < 0:
+                _lib.check(n, "gwen_gnn_forward_scratch_floats")
+            self._scratch = torch.empty(max(n, 4), dtype=torch.float32, device=dev)
+            self._scratch_key = key
+        return self._scratch
+
+    def run(self, x: Tensor, out: Optional[Tensor] = None,
+            events: Optional[KernelEvents] = None) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("gwen_amd: x must live on a HIP device (no CPU fallback)")
+        if x.dtype != torch.float32:
+            raise TypeError(f"gwen_amd: x must be float32 (got {x.dtype})")
+        x = x.contiguous()
+        if x.dim() == 2:
+            members = 1
+        elif x.dim() == 3:
+            members = x.size(0)
+        else:
+            raise ValueError(f"x must be [N, C] or [members, N, C], got {tuple(x.shape)}")
+        n = self.graph.num_nodes
+        if x.size(-2) != n or x.size(-1) != self.fin:
+            raise ValueError(f"x is {tuple(x.shape)}, expected [..., {n}, {self.fin}]")
+        dev = x.device
+        if out is None:
+            out = torch.empty(*x.shape[:-1], self.fout, dtype=torch.float32, device=dev)
+        scratch = self._scratch_for(members, dev)
+        g = self.graph
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gwen_gnn_forward_f32(
+                _ptr(g.rowptr), _ptr(g.col), _ptr(g.val), n, self.desc, len(self.desc), _ptr(x),
+                _ptr(out), _ptr(scratch), scratch.numel(), members, _stream(dev),
+                None if events is None else events._ev,
+                None if events is None else events.info,
+                0 if events is None else events.max_launches,
+                None if events is None else C.byref(events.n))
+        _lib.check(rc, "gwen_gnn_forward_f32")
+        return out

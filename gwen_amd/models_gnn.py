@@ -20,6 +20,7 @@ from dataclasses import dataclass
 import torch
 from torch import Tensor, nn
 
+from .forward import StackForward
 from .gcn_conv import GCNConv
 from .graph import GraphCSR, default_cache
 
@@ -115,7 +116,19 @@ class GNNModel(nn.Module):
         return default_cache().get(edge_index, num_nodes, None, add_self_loops=True,
                                    improved=False, normalize=True)
 
+    def stack(self):
+        """The six layers the forward uses, in order, as (weight, bias, relu, order)."""
+        d, u = self.conv_layers.down_conv_layers, self.conv_layers.up_conv_layers
+        used = [(d.conv1, True), (d.conv2, True), (d.conv3, True), (u.upconv3, True),
+                (u.upconv4, True), (u.upconv5, False)]
+        return [(c.lin.weight, c.bias, relu, c.order) for c, relu in used]
+
     def forward(self, x: Tensor, edge_index) -> Tensor:
         if not isinstance(edge_index, GraphCSR):
             edge_index = self.prepare(edge_index, x.size(-2))
-        return self.conv_layers(x, edge_index)
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return self.conv_layers(x, edge_index)          # per-layer autograd Functions
+        # inference: the whole stack from one host call (gwen_gnn_forward_f32)
+        return StackForward(self.stack(), edge_index).run(x)

@@ -79,6 +79,34 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool 
     return out
 
 
+def layer_supported(fin: int, fout: int) -> bool:
+    return bool(_lib.lib().gwen_gcn_layer_supported(fin, fout))
+
+
+def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
+                relu: bool = False) -> Tensor:
+    """K4: act((A~ x) W^T + b) in one launch (widths in {16,32,64,128})."""
+    _require(x, "x")
+    _require(weight, "weight")
+    x = x.contiguous()
+    weight = weight.contiguous()
+    m, n, fin = _rows2d(x)
+    fout = weight.size(0)
+    if n != graph.num_nodes or weight.size(1) != fin:
+        raise ValueError("shape mismatch between x, weight and the graph")
+    if bias is not None:
+        _require(bias, "bias")
+        bias = bias.contiguous()
+    out = torch.empty(*x.shape[:-1], fout, dtype=torch.float32, device=x.device)
+    dev = x.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_layer_f32(
+            _ptr(graph.rowptr), _ptr(graph.col), _ptr(graph.val), _ptr(x), _ptr(weight), _ptr(bias),
+            _ptr(out), n, fin, fout, fin, fout, m, n * fin, n * fout, int(relu), _stream(dev))
+    _lib.check(rc, "gwen_gcn_layer_f32")
+    return out
+
+
 def _grad_workspace(rows: int, fin: int, fout: int, dev) -> Tensor:
     n = int(_lib.lib().gwen_gcn_grad_workspace_floats(rows, fin, fout))
     return torch.empty(n, dtype=torch.float32, device=dev)
@@ -124,10 +152,11 @@ def relu_backward(y: Tensor, g: Tensor) -> Tensor:
 class GCNLayerFunction(torch.autograd.Function):
     """act(A~ (x W^T) + b): forward and backward entirely on the HIP kernels.
 
-    Order of the two linear maps is chosen per layer: transform-first (x W^T, then aggregate at width
-    Fout -- what PyG does) when Fout <= Fin, aggregate-first (A~ x at width Fin, then the projection
-    with the bias/ReLU epilogue) when Fin < Fout, so the gather always runs at the narrower width.
-    Both equal the reference's result up to fp32 rounding order (A~ is linear).
+    ``order``: "fused" = K4, one launch (chosen by "auto" whenever the widths allow); otherwise the
+    two linear maps run as two launches, transform-first (x W^T, then aggregate at width Fout -- what
+    PyG does) when Fout <= Fin, aggregate-first (A~ x at width Fin, then the projection with the
+    bias/ReLU epilogue) when Fin < Fout, so the gather always runs at the narrower width.
+    All three equal the reference's result up to fp32 rounding order (A~ is linear).
     """
 
     @staticmethod
@@ -135,8 +164,14 @@ class GCNLayerFunction(torch.autograd.Function):
                 relu: bool, order: str) -> Tensor:
         fout, fin = weight.shape
         if order == "auto":
-            order = "aggregate_first" if fin < fout else "transform_first"
-        if order == "transform_first":
+            if layer_supported(fin, fout):
+                order = "fused"
+            else:
+                order = "aggregate_first" if fin < fout else "transform_first"
+        if order == "fused":
+            out = layer_fused(graph, x, weight, bias, relu)
+            saved_in = x
+        elif order == "transform_first":
             h = linear(x, weight)
             out = propagate(graph, h, bias, relu)
             saved_in = x
@@ -158,7 +193,7 @@ class GCNLayerFunction(torch.autograd.Function):
             g = relu_backward(out, g)
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         gx = gw = None
-        if ctx.order == "transform_first":
+        if ctx.order in ("transform_first", "fused"):                # out = act(A~ x W^T + b) either way
             gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x

@@ -91,6 +91,67 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
                         gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K4  one whole GCNConv layer (+ReLU) in a single launch, aggregate-first:
+ *        out = act( (A~ x) W^T + bias )        (== A~ (x W^T) + bias, A~ linear)
+ * Gathers x at width Fin, keeps the aggregated tile in LDS, contracts it with W on the fp32 MFMA,
+ * and stores once at width Fout: no [N, Fout] intermediate `h` goes through HBM.
+ * Supported widths: Fin, Fout in {16, 32, 64, 128} with W and the wave tiles fitting 160 KiB of LDS
+ * (gwen_gcn_layer_supported() says; otherwise GWEN_EINVAL: use K3 + K2).  Same alignment rules as K2.
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
+                       const float *W, const float *bias, float *out, int64_t N, int64_t Fin,
+                       int64_t Fout, int64_t ldx, int64_t ldo, int64_t members, int64_t mstride_x,
+                       int64_t mstride_o, int relu, gwen_stream_t stream);
+int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-stack forward == GNNModel.forward (/root/reference/src/gwen/models_gnn.py:292-303 ->
+ * :241-258 -> :135-157, :189-212): every layer of the stack issued back to back from one host
+ * call, so the host never limits the device (the reference pays ~15 eager launches per layer).
+ *
+ * layers (HOST array): per layer W [fout, fin], bias [fout] or NULL (device pointers), relu 0/1 and
+ *   order: GWEN_ORDER_AUTO picks K4 when gwen_gcn_layer_supported(fin, fout), otherwise
+ *   transform-first (K3 then K2) when fout <= fin, aggregate-first (K2 then K3) when fin < fout.
+ * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
+ * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
+ * events (HOST array of hipEvent_t, or NULL): if given, events[2i] / events[2i+1] are recorded on
+ *   `stream` right before / after kernel launch i; info[i] (HOST, or NULL) says what launch i was.
+ *   n_launches (HOST, or NULL) receives the number of launches; max_launches bounds both arrays.
+ * ------------------------------------------------------------------------------------------- */
+#define GWEN_ORDER_AUTO (-1)
+#define GWEN_ORDER_TRANSFORM_FIRST 0
+#define GWEN_ORDER_AGGREGATE_FIRST 1
+#define GWEN_ORDER_FUSED 2
+#define GWEN_KIND_LINEAR 3      /* K3 */
+#define GWEN_KIND_PROPAGATE 2   /* K2 */
+#define GWEN_KIND_LAYER 4       /* K4 */
+
+typedef struct gwen_layer_desc {
+  const float *W;
+  const float *bias;
+  int32_t fin, fout, relu, order;
+} gwen_layer_desc;
+
+typedef struct gwen_launch_info {
+  int32_t kind, layer, fin, fout;
+} gwen_launch_info;
+
+int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members, const gwen_layer_desc *layers,
+                                        int32_t n_layers);
+int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+                         const gwen_layer_desc *layers, int32_t n_layers, const float *x, float *out,
+                         float *scratch, int64_t scratch_floats, int64_t members,
+                         gwen_stream_t stream, void **events, gwen_launch_info *info,
+                         int32_t max_launches, int32_t *n_launches);
+
+/* hipEvent plumbing for callers without a HIP binding (bench.py times kernels with these, on the
+ * stream the kernels are launched on). */
+int gwen_event_create(void **event /* host out */);
+int gwen_event_destroy(void *event);
+int gwen_event_synchronize(void *event);
+int gwen_event_elapsed_ms(void *start, void *stop, float *ms /* host out */);
+
+/* ---------------------------------------------------------------------------------------------
  * Backward pieces (autograd of the layer; the reference trains through it:
  * /root/reference/src/gwen/models_gnn.py:372 loss.backward()).
  *   grad_W[Fout,Fin] = g^T @ x   (g [rows,Fout], x [rows,Fin]); deterministic two-stage reduce.

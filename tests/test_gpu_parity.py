@@ -148,8 +148,9 @@ def test_linear(ga, cref, rows, fin, fout):
 # ------------------------------------------------------------------------------------------------
 # one layer and the whole model against the torch oracle (the "reference PyTorch CPU path")
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
-@pytest.mark.parametrize("fin,fout", [(8, 8), (64, 32), (16, 32), (64, 64), (256, 256), (6, 10)])
+@pytest.mark.parametrize("order", ["transform_first", "aggregate_first", "auto"])
+@pytest.mark.parametrize("fin,fout", [(8, 8), (64, 32), (16, 32), (64, 64), (256, 256), (6, 10),
+                                      (128, 128), (16, 128), (128, 16), (32, 32)])
 @pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[7]], ids=[IDS[0], IDS[1], IDS[7]])
 def test_layer_vs_oracle(ga, cref, case, fin, fout, order):
     from oracle import gcn_oracle as O
@@ -204,6 +205,64 @@ def test_model_members_axis(ga):
         batched = model(x, ei)
         single = torch.stack([model(x[i], ei) for i in range(4)])
     assert torch.equal(batched, single)
+
+
+# ------------------------------------------------------------------------------------------------
+# K4 fused layer and the whole-stack launcher
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fin,fout", [(16, 16), (16, 32), (32, 16), (64, 64), (64, 32), (32, 64),
+                                      (128, 64), (64, 128), (128, 128), (16, 128)])
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_fused_layer_vs_oracle(ga, cref, case, fin, fout):
+    from gwen_amd import ops
+    name, n, ei = case
+    assert ops.layer_supported(fin, fout)
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(fin, fout)
+    g = ga.prepare_graph(ei.to(DEV), n)
+    ref64 = torch.from_numpy(cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True))
+    got = ops.layer_fused(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True).cpu()
+    assert rel_err(got, ref64) <= 1e-5
+    again = ops.layer_fused(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True).cpu()
+    assert torch.equal(got, again)                               # atomic-free => reproducible
+    nob = ops.layer_fused(g, x.to(DEV), w.to(DEV)).cpu()
+    ref_nob = torch.from_numpy(cref.conv(x.numpy(), ei.numpy(), w.numpy(), None, f64=True))
+    assert rel_err(nob, ref_nob) <= 1e-5
+
+
+def test_fused_layer_unsupported_widths_are_refused(ga):
+    from gwen_amd import ops, _lib
+    assert not ops.layer_supported(8, 8) and not ops.layer_supported(256, 256)
+    assert not ops.layer_supported(24, 64)
+    g = ga.prepare_graph(CASES[5][2].to(DEV), 3)
+    with pytest.raises(_lib.GwenHipError):
+        ops.layer_fused(g, torch.zeros(3, 24, device=DEV), torch.zeros(64, 24, device=DEV))
+
+
+@pytest.mark.parametrize("members", [1, 3])
+@pytest.mark.parametrize("C,H", [(64, 64), (8, 16), (20, 48), (16, 256)])
+def test_stack_forward_equals_layer_by_layer(ga, members, C, H):
+    """gwen_gnn_forward_f32 (one host call) == the per-layer autograd path, bit for bit."""
+    m = ga.geodesic_mesh(7)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(1, 1, C, C, H)).to(DEV)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    x = torch.randn(members, m.num_nodes, C, device=DEV)
+    x = x[0] if members == 1 else x
+    g = model.prepare(ei, m.num_nodes)
+    with torch.no_grad():
+        one_call = model(x, g)
+    layered = model.conv_layers(x.clone().requires_grad_(), g).detach()
+    assert torch.equal(one_call, layered)
+    ev = ga.KernelEvents(12)
+    again = ga.StackForward(model.stack(), g).run(x, events=ev)
+    assert torch.equal(again, one_call)
+    d = ev.durations()
+    assert 6 <= len(d) <= 12 and all(t >= 0 for *_, t in d)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -274,12 +333,12 @@ def test_properties_full_size(ga):
 # ------------------------------------------------------------------------------------------------
 # backward: gradients against torch autograd through the oracle
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("order", ["transform_first", "aggregate_first"])
+@pytest.mark.parametrize("order,fin,fout", [("transform_first", 24, 40), ("aggregate_first", 24, 40),
+                                            ("fused", 32, 64), ("fused", 64, 16)])
 @pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[7]], ids=[IDS[0], IDS[1], IDS[7]])
-def test_layer_backward(ga, case, order):
+def test_layer_backward(ga, case, order, fin, fout):
     from oracle import gcn_oracle as O
     name, n, ei = case
-    fin, fout = 24, 40
     x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED))
     w, b = make_params(fin, fout)
     gout = torch.randn(n, fout, generator=torch.Generator().manual_seed(SEED + 1))
