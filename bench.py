@@ -51,6 +51,10 @@ def parse():
     p.add_argument("--reorder", default="morton", choices=["none", "morton"])
     p.add_argument("--order", default="auto", choices=["auto", "unfused"],
                    help="auto: K4 fused layer where the widths allow; unfused: K3 + K2 per layer")
+    p.add_argument("--event-stride", type=int, default=4,
+                   help="record per-kernel hipEvents on every n-th timed step (each record costs "
+                        "the stream a few microseconds, so instrumenting every step would slow the "
+                        "steps being timed)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return p.parse_args()
@@ -117,8 +121,8 @@ def main():
     # ---- the whole stack behind one C call; hipEvents around every kernel launch ----------------
     plan = gwen_amd.StackForward(model.stack(), graph)
     out = plan.run(x)                                                 # allocates scratch + output
-    n_sets = min(args.steps, 256)                                     # event sets (one per timed step,
-    stride = (args.steps + n_sets - 1) // n_sets                      #  every stride-th step beyond 256)
+    stride = max(1, args.event_stride)                                # events on every stride-th step
+    n_sets = (args.steps + stride - 1) // stride
     ev_sets = [gwen_amd.KernelEvents(2 * layers) for _ in range(n_sets)]
 
     def step(ev=None):

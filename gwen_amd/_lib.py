@@ -45,6 +45,8 @@ SIGNATURES = {
     "gwen_gcn_prep": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, C.c_size_t, _vp]),
     "gwen_gcn_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "gwen_gcn_group8_capacity": (_i64, [_i64, _i64]),
+    "gwen_gcn_group8": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gwen_gcn_propagate_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                       _i64, _i64, _int, _vp]),
     "gwen_gcn_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
@@ -52,7 +54,7 @@ SIGNATURES = {
                                   _i64, _i64, _i64, _int, _vp]),
     "gwen_gcn_layer_supported": (_int, [_i64, _i64]),
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
-    "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
+    "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
                                     C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]),
     "gwen_event_create": (_int, [C.POINTER(C.c_void_p)]),

@@ -55,7 +55,9 @@ extern "C" int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members,
 }
 
 extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
-                                    int64_t N, const gwen_layer_desc *layers, int32_t n_layers,
+                                    const int32_t *g_rowptr, const int32_t *g_col,
+                                    const float *g_val, int64_t N, const gwen_layer_desc *layers,
+                                    int32_t n_layers,
                                     const float *x, float *out, float *scratch,
                                     int64_t scratch_floats, int64_t members, gwen_stream_t stream,
                                     void **events, gwen_launch_info *info, int32_t max_launches,
@@ -93,7 +95,8 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
     const int64_t fi = L.fin, fo = L.fout;
     if (o == GWEN_ORDER_FUSED) {
       GWEN_TRY(before(GWEN_KIND_LAYER, i, fi, fo));
-      GWEN_TRY(gwen_gcn_layer_f32(rowptr, col, val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
+      if (!g_rowptr || !g_col || !g_val) return GWEN_EINVAL;
+      GWEN_TRY(gwen_gcn_layer_f32(g_rowptr, g_col, g_val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
                                   members, N * fi, N * fo, L.relu, stream));
       GWEN_TRY(after());
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {

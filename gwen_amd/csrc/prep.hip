@@ -14,6 +14,7 @@
 #include "common.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
@@ -164,6 +165,36 @@ __global__ void k_tfill(const uint64_t *__restrict__ ks, const int32_t *__restri
   t_val[i] = val[s];
 }
 
+// ---- grouped layout (rows padded to whole groups of 8 entries) ------------------------------
+__global__ void k_glen(const int32_t *__restrict__ rowptr, int64_t N, int32_t *__restrict__ glen) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r > N) return;
+  glen[r] = r < N ? ((rowptr[r + 1] - rowptr[r] + 7) & ~7) : 0;
+}
+
+// 8 lanes per row copy its entries and append the padding (weight 0, column of the row's first
+// entry: a row that is already part of the sum); lane group N writes the all-zero null group.
+__global__ void k_gfill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                        const float *__restrict__ val, const int32_t *__restrict__ g_rowptr,
+                        int64_t N, int32_t *__restrict__ g_col, float *__restrict__ g_val) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t r = t >> 3;
+  int lane = (int)(t & 7);
+  if (r > N) return;
+  if (r == N) {                      // null group right behind the last row
+    g_col[g_rowptr[N] + lane] = 0;
+    g_val[g_rowptr[N] + lane] = 0.0f;
+    return;
+  }
+  const int32_t s0 = rowptr[r], len = rowptr[r + 1] - s0;
+  const int32_t g0 = g_rowptr[r], glen = g_rowptr[r + 1] - g0;
+  const int32_t first = len > 0 ? col[s0] : 0;
+  for (int32_t p = lane; p < glen; p += 8) {
+    g_col[g0 + p] = p < len ? col[s0 + p] : first;
+    g_val[g0 + p] = p < len ? val[s0 + p] : 0.0f;
+  }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
 struct WsLayout {
@@ -287,5 +318,35 @@ extern "C" int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, con
     k_tfill<<<blocks_for(cap), kThreads, 0, stream>>>(ks, rowptr, val, cap, N, sbits, t_col, t_val);
     GWEN_LAUNCH_CHECK();
   }
+  return GWEN_OK;
+}
+
+extern "C" int64_t gwen_gcn_group8_capacity(int64_t N, int64_t cap) {
+  if (N < 0 || cap < 0) return GWEN_EINVAL;
+  return cap + 7 * N + 8;            // every row padded by at most 7 entries + the null group
+}
+
+extern "C" int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const float *val,
+                               int64_t N, int64_t cap, int32_t *g_rowptr, int32_t *g_col,
+                               float *g_val, void *workspace, size_t workspace_bytes,
+                               gwen_stream_t stream_) {
+  if (N < 0 || cap < 0 || !rowptr || !g_rowptr || !g_col || !g_val) return GWEN_EINVAL;
+  if (cap > 0 && (!col || !val)) return GWEN_EINVAL;
+  if (cap + 7 * N + 8 >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
+  hipStream_t stream = gwen_stream(stream_);
+  const size_t glen_bytes = gwen_align_up(sizeof(int32_t) * (size_t)(N + 1), 256);
+  size_t tb = 0;
+  GWEN_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, (int32_t *)nullptr, (int32_t *)nullptr, 0,
+                                         (size_t)(N + 1), rocprim::plus<int32_t>(), stream));
+  if (!workspace || workspace_bytes < glen_bytes + tb) return GWEN_ENOSPACE;
+  int32_t *glen = static_cast<int32_t *>(workspace);
+  void *temp = static_cast<char *>(workspace) + glen_bytes;
+  k_glen<<<blocks_for(N + 1), kThreads, 0, stream>>>(rowptr, N, glen);
+  GWEN_LAUNCH_CHECK();
+  GWEN_HIP_CHECK(rocprim::exclusive_scan(temp, tb, glen, g_rowptr, 0, (size_t)(N + 1),
+                                         rocprim::plus<int32_t>(), stream));
+  k_gfill<<<blocks_for((N + 1) * 8), kThreads, 0, stream>>>(rowptr, col, val, g_rowptr, N, g_col,
+                                                            g_val);
+  GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }

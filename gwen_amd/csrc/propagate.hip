@@ -50,17 +50,22 @@ __device__ inline typename Vec<V>::T vrelu(typename Vec<V>::T v) {
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
 
-template <int G, int V>
+template <int G, int V, bool REMAP>
 __global__ __launch_bounds__(kBlock) void k_propagate(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ h, const float *__restrict__ bias,
     float *__restrict__ out, int64_t n_items, int32_t nchunks, int32_t F, int64_t ldh, int64_t ldo,
     int64_t mstride_h, int64_t mstride_o, int relu) {
   using VT = typename Vec<V>::T;
-  const int64_t item = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  int64_t lb = blockIdx.x;
+  if constexpr (REMAP) {   // blocks sharing an XCD (blockIdx % 8) take neighbouring rows
+    const int64_t nb = gridDim.x, xcd = lb & 7, q8 = nb >> 3, r8 = nb & 7;
+    lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lb >> 3);
+  }
+  const int64_t item = lb * (kBlock / G) + threadIdx.x / G;
   const int lane = threadIdx.x % G;
   if (item >= n_items) return;
-  const int64_t r = item / nchunks;
+  const int64_t r = nchunks == 1 ? item : item / nchunks;
   const int32_t f = (int32_t)(item - r * nchunks) * (G * V) + lane * V;
   if (f >= F) return;
   const float *hm = h + (int64_t)blockIdx.y * mstride_h + f;
@@ -99,9 +104,16 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
   const int64_t blocks = (n_items + per_block - 1) / per_block;
   if (blocks > 0x7fffffffLL || members > 65535) return GWEN_ERANGE;
   dim3 grid((unsigned)blocks, (unsigned)members);
-  k_propagate<G, V><<<grid, kBlock, 0, stream>>>(rowptr, col, val, h, bias, out, n_items,
-                                                 (int32_t)nchunks, (int32_t)F, ldh, ldo, msh, mso,
-                                                 relu);
+  // XCD remap pays when rows of one XCD are neighbours (one chunk per row); with several feature
+  // chunks per row the items of a row already sit side by side
+  if (nchunks == 1)
+    k_propagate<G, V, true><<<grid, kBlock, 0, stream>>>(rowptr, col, val, h, bias, out, n_items,
+                                                         (int32_t)nchunks, (int32_t)F, ldh, ldo, msh,
+                                                         mso, relu);
+  else
+    k_propagate<G, V, false><<<grid, kBlock, 0, stream>>>(rowptr, col, val, h, bias, out, n_items,
+                                                          (int32_t)nchunks, (int32_t)F, ldh, ldo,
+                                                          msh, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }

@@ -44,6 +44,7 @@ class GraphCSR:
     status: Tensor                 # int32 [2]     [bad-index flag, E']
     _workspace: Optional[Tensor] = field(default=None, repr=False)
     _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
+    _grouped: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -53,14 +54,20 @@ class GraphCSR:
         """Number of stored entries E' (synchronises)."""
         return int(self.status[1].item())
 
+    def grouped(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """Rows padded to whole 8-entry groups (rowptr, col, val) for K4; built on first use."""
+        if self._grouped is None:
+            self._grouped = _grouped_impl(self)
+        return self._grouped
+
     def transposed(self) -> Tuple[Tensor, Tensor, Tensor]:
         """CSR by SOURCE node (rowptr, col = target, val) for the backward pass; built on first use."""
         if self._transposed is None:
-            n, cap = self.num_nodes, self.col.numel()
+            n, cap = self.num_nodes, self.num_nodes + self.num_edges
             dev = self.device
             t_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-            t_col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-            t_val = torch.empty(max(cap, 1), dtype=torch.float32, device=dev)
+            t_col = torch.empty(max(cap, 1) + 8, dtype=torch.int32, device=dev)
+            t_val = torch.empty(max(cap, 1) + 8, dtype=torch.float32, device=dev)
             ws = self._workspace
             if ws is None:
                 ws = _alloc_workspace(n, self.num_edges, dev)
@@ -71,6 +78,22 @@ class GraphCSR:
             _lib.check(rc, "gwen_gcn_transpose")
             self._transposed = (t_rowptr, t_col, t_val)
         return self._transposed
+
+
+def _grouped_impl(g: "GraphCSR") -> Tuple[Tensor, Tensor, Tensor]:
+    n, cap = g.num_nodes, g.num_nodes + g.num_edges
+    dev = g.device
+    gcap = int(_lib.lib().gwen_gcn_group8_capacity(n, cap))
+    g_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    g_col = torch.empty(gcap, dtype=torch.int32, device=dev)
+    g_val = torch.empty(gcap, dtype=torch.float32, device=dev)
+    ws = g._workspace if g._workspace is not None else _alloc_workspace(n, g.num_edges, dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_group8(_ptr(g.rowptr), _ptr(g.col), _ptr(g.val), n, cap,
+                                        _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(ws),
+                                        ws.numel(), _stream(dev))
+    _lib.check(rc, "gwen_gcn_group8")
+    return g_rowptr, g_col, g_val
 
 
 def _alloc_workspace(n: int, e: int, device: torch.device) -> Tensor:
@@ -110,7 +133,7 @@ def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tens
             raise RuntimeError("edge_weight and edge_index are on different devices")
         ew = edge_weight.detach().to(torch.float32).contiguous()
     n = int(num_nodes)
-    cap = max(e + n, 1)
+    cap = max(e + n, 1) + 8          # 8 entries of slack: K4 reads indices 8 at a time
     rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     col = torch.empty(cap, dtype=torch.int32, device=dev)
     val = torch.empty(cap, dtype=torch.float32, device=dev)

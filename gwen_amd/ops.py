@@ -99,9 +99,10 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
         bias = bias.contiguous()
     out = torch.empty(*x.shape[:-1], fout, dtype=torch.float32, device=x.device)
     dev = x.device
+    g_rowptr, g_col, g_val = graph.grouped()
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_layer_f32(
-            _ptr(graph.rowptr), _ptr(graph.col), _ptr(graph.val), _ptr(x), _ptr(weight), _ptr(bias),
+            _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(weight), _ptr(bias),
             _ptr(out), n, fin, fout, fin, fout, m, n * fin, n * fout, int(relu), _stream(dev))
     _lib.check(rc, "gwen_gcn_layer_f32")
     return out

@@ -65,6 +65,17 @@ int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, const float *v
                        int64_t cap, int32_t *t_rowptr, int32_t *t_col, float *t_val,
                        void *workspace, size_t workspace_bytes, gwen_stream_t stream);
 
+/* Grouped layout of a prepared graph for K4: every row padded to a whole number of 8-entry groups
+ * (padding entries carry weight 0 and the column of the row's first entry), so the kernel reads
+ * indices and weights as aligned 32-byte groups and needs no per-entry bounds logic.
+ *   g_rowptr int32 [N+1] (entry offsets, multiples of 8), g_col / g_val [gwen_gcn_group8_capacity()],
+ *   followed at g_rowptr[N] by one all-zero "null group" (col 0, weight 0).
+ * workspace: as for gwen_gcn_prep. */
+int64_t gwen_gcn_group8_capacity(int64_t N, int64_t cap);
+int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+                    int64_t cap, int32_t *g_rowptr, int32_t *g_col, float *g_val, void *workspace,
+                    size_t workspace_bytes, gwen_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  fused propagate == MessagePassing.propagate (message w~ * x_j, aggregate add at target)
  *     + bias add (GCNConv.forward) + torch.relu (/root/reference/src/gwen/models_gnn.py:147-149,
@@ -95,6 +106,8 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
  *        out = act( (A~ x) W^T + bias )        (== A~ (x W^T) + bias, A~ linear)
  * Gathers x at width Fin, keeps the aggregated tile in LDS, contracts it with W on the fp32 MFMA,
  * and stores once at width Fout: no [N, Fout] intermediate `h` goes through HBM.
+ * rowptr/col/val here are the GROUPED arrays of gwen_gcn_group8() (rows in whole groups of 8, null
+ * group at rowptr[N]); x rows must be contiguous (ldx == Fin) and N * Fin * 4 < 2^32.
  * Supported widths: Fin, Fout in {16, 32, 64, 128} with W and the wave tiles fitting 160 KiB of LDS
  * (gwen_gcn_layer_supported() says; otherwise GWEN_EINVAL: use K3 + K2).  Same alignment rules as K2.
  * ------------------------------------------------------------------------------------------- */
@@ -112,6 +125,8 @@ int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
  * layers (HOST array): per layer W [fout, fin], bias [fout] or NULL (device pointers), relu 0/1 and
  *   order: GWEN_ORDER_AUTO picks K4 when gwen_gcn_layer_supported(fin, fout), otherwise
  *   transform-first (K3 then K2) when fout <= fin, aggregate-first (K2 then K3) when fin < fout.
+ * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4 layers;
+ *   may be NULL when no layer resolves to K4).
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
  * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
  * events (HOST array of hipEvent_t, or NULL): if given, events[2i] / events[2i+1] are recorded on
@@ -138,7 +153,8 @@ typedef struct gwen_launch_info {
 
 int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members, const gwen_layer_desc *layers,
                                         int32_t n_layers);
-int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                         const int32_t *g_rowptr, const int32_t *g_col, const float *g_val, int64_t N,
                          const gwen_layer_desc *layers, int32_t n_layers, const float *x, float *out,
                          float *scratch, int64_t scratch_floats, int64_t members,
                          gwen_stream_t stream, void **events, gwen_launch_info *info,

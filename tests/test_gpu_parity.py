@@ -91,6 +91,27 @@ def test_transpose_matches_numpy(ga):
     assert t_val[:nnz].tobytes() == val[order].tobytes()
 
 
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_grouped_layout(ga, case):
+    """gwen_gcn_group8: same entries per row, rows padded to whole groups of 8 with weight 0 and a
+    column that is already in the row, null group behind the last row."""
+    name, n, ei = case
+    g = ga.prepare_graph(ei.to(DEV), n)
+    rp, col, val = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy()
+    grp, gcol, gval = (t.cpu().numpy() for t in g.grouped())
+    assert grp[0] == 0 and (np.diff(grp) % 8 == 0).all()
+    for r in range(n):
+        ln = rp[r + 1] - rp[r]
+        gl = grp[r + 1] - grp[r]
+        assert gl == (ln + 7) // 8 * 8
+        np.testing.assert_array_equal(gcol[grp[r]:grp[r] + ln], col[rp[r]:rp[r + 1]])
+        assert gval[grp[r]:grp[r] + ln].tobytes() == val[rp[r]:rp[r + 1]].tobytes()
+        assert (gval[grp[r] + ln:grp[r + 1]] == 0).all()
+        if ln:
+            assert (gcol[grp[r] + ln:grp[r + 1]] == col[rp[r]]).all()
+    assert (gcol[grp[n]:grp[n] + 8] == 0).all() and (gval[grp[n]:grp[n] + 8] == 0).all()
+
+
 # ------------------------------------------------------------------------------------------------
 # K2: fused propagate, bit-exact against the sequential C oracle
 # ------------------------------------------------------------------------------------------------
