@@ -167,10 +167,21 @@ def main():
     b_alg = algorithmic_bytes(kind, n, e, fin, fout) * m_local
     avg_s = total_s / launches
     achieved = b_alg / avg_s / 1e9
+    # HBM-side bytes per launch of that kernel from the committed PMC passes (tools/profile_bench.sh +
+    # tools/collect_traffic.py; FETCH_SIZE and WRITE_SIZE need separate rocprofv3 passes)
+    traffic = None
+    try:
+        tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
+        tag = {"layer": f"k_layer<{fin}, {fout},", "linear": "k_linear<", "propagate": "k_propagate<"}[kind]
+        hits = [v["hbm_bytes_per_launch"] for k_, v in tf.items() if k_.startswith(tag)]
+        if hits and (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1):
+            traffic = hits[0]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": round(avg_s * 1e6, 2),
+        "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": round(avg_s * 1e6, 2),
         "launches": launches,
         "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())},
     }
