@@ -55,6 +55,9 @@ def parse():
                    help="record per-kernel hipEvents on every n-th timed step (each record costs "
                         "the stream a few microseconds, so instrumenting every step would slow the "
                         "steps being timed)")
+    p.add_argument("--graph", action="store_true",
+                   help="replay a captured hipGraph per step instead of issuing the 6 launches from the "
+                        "C launcher (measured slower here: one graph launch costs more than 6 direct ones)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return p.parse_args()
@@ -125,8 +128,16 @@ def main():
     n_sets = (args.steps + stride - 1) // stride
     ev_sets = [gwen_amd.KernelEvents(2 * layers) for _ in range(n_sets)]
 
+    graphed = gwen_amd.GraphedForward(plan, x) if args.graph else None
+    if graphed is not None:
+        out = graphed.out
+
     def step(ev=None):
-        return plan.run(x, out=out, events=ev)
+        # every step is the same work; steps that carry hipEvents are issued launch by launch (events
+        # cannot be read back from inside a graph), all others replay the captured hipGraph
+        if ev is not None or graphed is None:
+            return plan.run(x, out=out, events=ev)
+        return graphed()
 
     def barrier():
         if world > 1:
@@ -134,6 +145,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:   # RCCL sets its rings/channels up on the first collective: keep that out of the timing
+        ensemble.gather_members(out if out.dim() == 3 else out.unsqueeze(0), members)
     torch.cuda.synchronize()
     barrier()
 
@@ -195,7 +208,7 @@ def main():
         "config": {"workload": f"c2: geodesic mesh nu={args.nu} N={n} E={e}, GNNModel forward "
                                f"C={c} H={h} (6 GCNConv layers), {m_local} member/GPU",
                    "nodes": n, "edges": e, "channels": c, "hidden": h, "layers": layers,
-                   "members": members, "node_order": args.reorder, "kernel_order": args.order,
+                   "members": members, "node_order": args.reorder, "kernel_order": args.order, "hip_graph": bool(args.graph),
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
         "members_per_s": members * args.steps / elapsed,
         "roofline": roofline,

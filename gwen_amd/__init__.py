@@ -5,7 +5,7 @@ UpConvLayers, GCNConvLayers, GNNModel, loss_func) plus the ``GCNConv`` layer it 
 torch-geometric (:19).  Kernels live in libgwen_hip.so (include/gwen_hip.h); build it with
 ``python -m gwen_amd.build``.
 """
-from .forward import KernelEvents, StackForward
+from .forward import GraphedForward, KernelEvents, StackForward
 from .gcn_conv import GCNConv, Linear
 from .graph import GraphCSR, GraphCache, default_cache, prepare_graph
 from .mesh import Mesh, complete_graph, geodesic_mesh
@@ -13,7 +13,7 @@ from .models_gnn import (DownConvLayers, GCNConvLayers, GNNConfig, GNNModel, UpC
                          loss_func)
 
 __all__ = [
-    "GCNConv", "Linear", "KernelEvents", "StackForward", "GraphCSR", "GraphCache", "default_cache", "prepare_graph", "Mesh",
+    "GCNConv", "Linear", "GraphedForward", "KernelEvents", "StackForward", "GraphCSR", "GraphCache", "default_cache", "prepare_graph", "Mesh",
     "complete_graph", "geodesic_mesh", "DownConvLayers", "GCNConvLayers", "GNNConfig", "GNNModel",
     "UpConvLayers", "loss_func",
 ]

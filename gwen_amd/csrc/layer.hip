@@ -22,6 +22,7 @@
 // Blocks are remapped so that the blocks sharing an XCD (blockIdx % 8) own neighbouring row ranges:
 // gathered rows are then re-used inside one 4 MiB L2 instead of being fetched by all eight.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -265,6 +266,10 @@ int launch_v(const int32_t *rowptr, const int32_t *col, const float *val, const 
   int64_t blocks = 256 * per_cu;
   const int64_t max_useful = (N + kTile * kWaves - 1) / (kTile * kWaves);
   if (blocks > max_useful) blocks = max_useful;     // small graphs: fewer than one tile per wave
+  if (const char *e = getenv("GWEN_K4_RPW")) {       // TUNING ONLY: rows per wave, many short blocks
+    const int64_t rpw = atoi(e);
+    if (rpw > 0) blocks = (N + rpw * kWaves - 1) / (rpw * kWaves);
+  }
   dim3 grid((unsigned)blocks, (unsigned)members);
   k_layer<FIN, FOUT, NW, MINW><<<grid, kThreads, C::lds_bytes, st>>>(
       rowptr, col, val, x, W, bias, out, (int32_t)N, ldx, ldo, msx, mso, relu);
@@ -278,6 +283,10 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
            const float *W, const float *bias, float *out, int64_t N, int64_t ldx, int64_t ldo,
            int64_t members, int64_t msx, int64_t mso, int relu, hipStream_t st) {
   constexpr int NWV = FIN >= 64 ? 8 : 4;
+  if (const char *e = getenv("GWEN_K4_WAVES"))
+    if (atoi(e) == 4)
+      return launch_v<FIN, FOUT, 4, 1>(rowptr, col, val, x, W, bias, out, N, ldx, ldo, members, msx,
+                                       mso, relu, st);
   return launch_v<FIN, FOUT, NWV, 1>(rowptr, col, val, x, W, bias, out, N, ldx, ldo, members, msx,
                                      mso, relu, st);
 }

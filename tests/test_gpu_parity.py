@@ -284,6 +284,11 @@ def test_stack_forward_equals_layer_by_layer(ga, members, C, H):
     assert torch.equal(again, one_call)
     d = ev.durations()
     assert 6 <= len(d) <= 12 and all(t >= 0 for *_, t in d)
+    graphed = ga.GraphedForward(ga.StackForward(model.stack(), g), x)      # hipGraph replay
+    assert torch.equal(graphed(), one_call)
+    x2 = torch.randn_like(x)
+    with torch.no_grad():
+        assert torch.equal(graphed(x2), model(x2, g))
 
 
 # ------------------------------------------------------------------------------------------------
