@@ -33,7 +33,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("layer", C.c_int32), ("fin", C.c_int32), ("fout", C.c_int32)]
 
 
-ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED = -1, 0, 1, 2
+ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
 KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER = 2, 3, 4
 KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer"}
 
@@ -51,7 +51,7 @@ SIGNATURES = {
                                       _i64, _i64, _int, _vp]),
     "gwen_gcn_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "gwen_gcn_layer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                  _i64, _i64, _i64, _int, _vp]),
+                                  _i64, _i64, _i64, _int, _int, _vp]),
     "gwen_gcn_layer_supported": (_int, [_i64, _i64]),
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
     "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,

@@ -31,7 +31,9 @@ int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t
     if (L.fin < 0 || L.fout < 0) return GWEN_EINVAL;
     if (i > 0 && layers[i - 1].fout != L.fin) return GWEN_EINVAL;
     const int o = resolve_order(L);
-    if (o == GWEN_ORDER_FUSED && !gwen_gcn_layer_supported(L.fin, L.fout)) return GWEN_EINVAL;
+    if ((o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) &&
+        !gwen_gcn_layer_supported(L.fin, L.fout))
+      return GWEN_EINVAL;
     if (i + 1 < n && L.fout > out_w) out_w = L.fout;
     if (o == GWEN_ORDER_TRANSFORM_FIRST && L.fout > tmp_w) tmp_w = L.fout;
     if (o == GWEN_ORDER_AGGREGATE_FIRST && L.fin > tmp_w) tmp_w = L.fin;
@@ -93,11 +95,12 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
     float *dst = (i + 1 == n_layers) ? out : buf[i & 1];
     const int o = resolve_order(L);
     const int64_t fi = L.fin, fo = L.fout;
-    if (o == GWEN_ORDER_FUSED) {
+    if (o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) {
       GWEN_TRY(before(GWEN_KIND_LAYER, i, fi, fo));
       if (!g_rowptr || !g_col || !g_val) return GWEN_EINVAL;
       GWEN_TRY(gwen_gcn_layer_f32(g_rowptr, g_col, g_val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
-                                  members, N * fi, N * fo, L.relu, stream));
+                                  members, N * fi, N * fo, L.relu,
+                                  o == GWEN_ORDER_FUSED_EXACT, stream));
       GWEN_TRY(after());
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));

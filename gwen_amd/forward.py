@@ -16,7 +16,8 @@ from . import _lib
 from .graph import GraphCSR, _ptr, _stream
 
 _ORDERS = {"auto": _lib.ORDER_AUTO, "transform_first": _lib.ORDER_TRANSFORM_FIRST,
-           "aggregate_first": _lib.ORDER_AGGREGATE_FIRST, "fused": _lib.ORDER_FUSED}
+           "aggregate_first": _lib.ORDER_AGGREGATE_FIRST, "fused": _lib.ORDER_FUSED,
+           "fused_exact": _lib.ORDER_FUSED_EXACT}
 
 
 class KernelEvents:

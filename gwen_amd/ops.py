@@ -84,8 +84,9 @@ def layer_supported(fin: int, fout: int) -> bool:
 
 
 def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-                relu: bool = False) -> Tensor:
-    """K4: act((A~ x) W^T + b) in one launch (widths in {16,32,64,128})."""
+                relu: bool = False, exact: bool = False) -> Tensor:
+    """K4: act((A~ x) W^T + b) in one launch (widths in {16,32,64,128}).  ``exact=False``: 3xbf16 split
+    contraction with fp32 accumulation (default); ``exact=True``: fp32-input MFMA."""
     _require(x, "x")
     _require(weight, "weight")
     x = x.contiguous()
@@ -103,7 +104,8 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_layer_f32(
             _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(weight), _ptr(bias),
-            _ptr(out), n, fin, fout, fin, fout, m, n * fin, n * fout, int(relu), _stream(dev))
+            _ptr(out), n, fin, fout, fin, fout, m, n * fin, n * fout, int(relu), int(exact),
+            _stream(dev))
     _lib.check(rc, "gwen_gcn_layer_f32")
     return out
 
@@ -169,8 +171,8 @@ class GCNLayerFunction(torch.autograd.Function):
                 order = "fused"
             else:
                 order = "aggregate_first" if fin < fout else "transform_first"
-        if order == "fused":
-            out = layer_fused(graph, x, weight, bias, relu)
+        if order in ("fused", "fused_exact"):
+            out = layer_fused(graph, x, weight, bias, relu, exact=(order == "fused_exact"))
             saved_in = x
         elif order == "transform_first":
             h = linear(x, weight)
@@ -194,7 +196,7 @@ class GCNLayerFunction(torch.autograd.Function):
             g = relu_backward(out, g)
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         gx = gw = None
-        if ctx.order in ("transform_first", "fused"):                # out = act(A~ x W^T + b) either way
+        if ctx.order in ("transform_first", "fused", "fused_exact"):                # out = act(A~ x W^T + b) either way
             gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x

@@ -104,8 +104,11 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
 /* ---------------------------------------------------------------------------------------------
  * K4  one whole GCNConv layer (+ReLU) in a single launch, aggregate-first:
  *        out = act( (A~ x) W^T + bias )        (== A~ (x W^T) + bias, A~ linear)
- * Gathers x at width Fin, keeps the aggregated tile in LDS, contracts it with W on the fp32 MFMA,
+ * Gathers x at width Fin, keeps the aggregated tile in LDS, contracts it with W on the matrix cores
  * and stores once at width Fout: no [N, Fout] intermediate `h` goes through HBM.
+ * exact = 0: the contraction runs as a 3-term bf16 split (x = hi + lo, fp32 accumulate; < 2^-15
+ *   relative per product, 8e-6 measured on the 6-layer model against a 1e-4 tolerance);
+ * exact = 1: fp32-input MFMA, bit-exact fp32 fmaf chains (about 1.3x slower at 64 -> 64).
  * rowptr/col/val here are the GROUPED arrays of gwen_gcn_group8() (rows in whole groups of 8, null
  * group at rowptr[N]); x rows must be contiguous (ldx == Fin) and N * Fin * 4 < 2^32.
  * Supported widths: Fin, Fout in {16, 32, 64, 128} with W and the wave tiles fitting 160 KiB of LDS
@@ -114,7 +117,7 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
 int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
                        const float *W, const float *bias, float *out, int64_t N, int64_t Fin,
                        int64_t Fout, int64_t ldx, int64_t ldo, int64_t members, int64_t mstride_x,
-                       int64_t mstride_o, int relu, gwen_stream_t stream);
+                       int64_t mstride_o, int relu, int exact, gwen_stream_t stream);
 int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
 
 /* ---------------------------------------------------------------------------------------------
@@ -136,7 +139,8 @@ int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
 #define GWEN_ORDER_AUTO (-1)
 #define GWEN_ORDER_TRANSFORM_FIRST 0
 #define GWEN_ORDER_AGGREGATE_FIRST 1
-#define GWEN_ORDER_FUSED 2
+#define GWEN_ORDER_FUSED 2         /* K4, 3xbf16 contraction */
+#define GWEN_ORDER_FUSED_EXACT 3   /* K4, fp32 MFMA contraction */
 #define GWEN_KIND_LINEAR 3      /* K3 */
 #define GWEN_KIND_PROPAGATE 2   /* K2 */
 #define GWEN_KIND_LAYER 4       /* K4 */
