@@ -52,13 +52,13 @@ __device__ inline void split_bf16(const float (&x)[K], typename BF<K>::T &hi, ty
   }
 }
 
-template <int FIN, int FOUT, bool SPLIT>
+template <int FIN, int FOUT, bool SPLIT, int BRMIN = 32>
 struct Cfg {
   static constexpr int G = FIN / 4, R = 64 / G;            // lanes per gathered row, rows per wave pass
   static constexpr int NJ = FOUT / 16;                     // 16-column output tiles
   static constexpr int NWB = NJ > 4 ? 8 : 4;               // waves per block
   static constexpr int RB = NWB * R;                       // rows gathered per block pass
-  static constexpr int BR = RB > 32 ? RB : 32;             // rows per block
+  static constexpr int BR = RB > BRMIN ? RB : BRMIN;       // rows per block
   static constexpr int NP = BR / RB;                       // gather passes per wave
   static constexpr int NT = BR / kTile;                    // 16-row tiles per block
   static constexpr int TSTEP = NWB / NJ;                   // row tiles are strided over the waves
@@ -71,13 +71,13 @@ struct Cfg {
   static_assert(NWB % NJ == 0, "waves must tile the output columns");
 };
 
-template <int FIN, int FOUT, bool SPLIT>
+template <int FIN, int FOUT, bool SPLIT, int BRMIN>
 __global__ __launch_bounds__((FOUT > 64 ? 512 : 256)) void k_layer(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int64_t ldo,
     int64_t mstride_x, int64_t mstride_o, int relu) {
-  using C = Cfg<FIN, FOUT, SPLIT>;
+  using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
   float *tile = reinterpret_cast<float *>(lds_raw);                      // exact: [BR][PF] fp32
   __bf16 *thi = reinterpret_cast<__bf16 *>(lds_raw);                     // split: [BR][PB] hi
@@ -209,11 +209,13 @@ template <int FIN, int FOUT, bool SPLIT>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st) {
-  using C = Cfg<FIN, FOUT, SPLIT>;
+  // rows per block: enough that W (read once per block) stays a small fraction of the gathered bytes
+  constexpr int BRMIN = FIN >= 128 ? 128 : 64;
+  using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
   const int64_t blocks = (N + C::BR - 1) / C::BR;
   dim3 grid((unsigned)blocks, (unsigned)members);
-  k_layer<FIN, FOUT, SPLIT><<<grid, C::NWB * 64, 0, st>>>(rowptr, col, val, x, W, bias, out,
-                                                           (int32_t)N, ldo, msx, mso, relu);
+  k_layer<FIN, FOUT, SPLIT, BRMIN><<<grid, C::NWB * 64, 0, st>>>(rowptr, col, val, x, W, bias, out,
+                                                                  (int32_t)N, ldo, msx, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
