@@ -71,6 +71,8 @@ def algorithmic_bytes(kind, n, e, fin, fout):
         return 4 * f * (e + 2 * n) + 8 * e + 8 * n
     if kind == "linear":         # K3: x read, h written, W read
         return 4 * n * (fin + fout) + 4 * fin * fout
+    if kind == "chain":          # K5: gather at fin (E edges + self-loop), store at fout, indices
+        return 4 * fin * (e + n) + 4 * fout * n + 8 * e + 8 * n
     if kind == "layer":          # K4: gather at fin (E edges + self-loop), store at fout, indices, W
         return 4 * fin * (e + n) + 4 * fout * n + 8 * e + 8 * n + 4 * fin * fout
     raise KeyError(kind)
@@ -185,7 +187,8 @@ def main():
     traffic = None
     try:
         tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
-        tag = {"layer": f"k_layer<{fin}, {fout},", "linear": "k_linear<", "propagate": "k_propagate<"}[kind]
+        tag = {"layer": f"k_layer<{fin}, {fout},", "chain": f"k_chain<{fin},", "linear": "k_linear<",
+               "propagate": "k_propagate<"}[kind]
         hits = [v["hbm_bytes_per_launch"] for k_, v in tf.items() if k_.startswith(tag)]
         if hits and (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1):
             traffic = hits[0]

@@ -34,8 +34,9 @@ class LaunchInfo(C.Structure):
 
 
 ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
-KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER = 2, 3, 4
-KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer"}
+KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN = 2, 3, 4, 5
+KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer",
+              KIND_CHAIN: "chain"}
 
 # name -> (restype, argtypes); mirrors include/gwen_hip.h one to one
 SIGNATURES = {
@@ -53,6 +54,9 @@ SIGNATURES = {
     "gwen_gcn_layer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _int, _int, _vp]),
     "gwen_gcn_layer_supported": (_int, [_i64, _i64]),
+    "gwen_gcn_chain_supported": (_int, [_i64, _i64, _i64, _int]),
+    "gwen_gcn_chain_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,
+                                  _int, _i64, _i64, _i64, _vp]),
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
     "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),

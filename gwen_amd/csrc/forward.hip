@@ -34,7 +34,7 @@ int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t
     if ((o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) &&
         !gwen_gcn_layer_supported(L.fin, L.fout))
       return GWEN_EINVAL;
-    if (i + 1 < n && L.fout > out_w) out_w = L.fout;
+    if (L.fout > out_w) out_w = L.fout;      // activations and pre-projected inputs of later layers
     if (o == GWEN_ORDER_TRANSFORM_FIRST && L.fout > tmp_w) tmp_w = L.fout;
     if (o == GWEN_ORDER_AGGREGATE_FIRST && L.fin > tmp_w) tmp_w = L.fin;
   }
@@ -89,20 +89,65 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
   };
 #define GWEN_TRY(expr) do { int _r = (expr); if (_r != GWEN_OK) return _r; } while (0)
 
+  // AUTO layer whose widths K4 takes and that shrinks: worth gathering at fout, i.e. transform-first
+  auto shrinking_auto = [&](int32_t i) {
+    return i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin;
+  };
+  const bool have_grouped = g_rowptr && g_col && g_val;
+
   const float *cur = x;
+  bool projected = false;          // cur holds h_i = a_i W_i^T (layer i's bias/ReLU still pending)
+  int32_t nbuf = 0;
   for (int32_t i = 0; i < n_layers; ++i) {
     const gwen_layer_desc &L = layers[i];
-    float *dst = (i + 1 == n_layers) ? out : buf[i & 1];
-    const int o = resolve_order(L);
+    const bool last = i + 1 == n_layers;
     const int64_t fi = L.fin, fo = L.fout;
+    if (projected) {
+      // layer i: propagate at width fo with its bias/ReLU; chain layer i+1's projection if it shrinks
+      const bool chain = !last && have_grouped && shrinking_auto(i + 1) &&
+                         gwen_gcn_chain_supported(fo, layers[i + 1].fout, 0, 1);
+      float *dst = (last) ? out : buf[nbuf++ & 1];
+      if (chain) {
+        GWEN_TRY(before(GWEN_KIND_CHAIN, i, fo, layers[i + 1].fout));
+        GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, layers[i + 1].W, nullptr, L.bias,
+                                    dst, N, fo, layers[i + 1].fout, 0, 1, L.relu, members, N * fo,
+                                    N * layers[i + 1].fout, stream));
+        GWEN_TRY(after());
+        projected = true;
+      } else {
+        GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fo, fo));
+        GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, cur, L.bias, dst, N, fo, fo, fo, members,
+                                        N * fo, N * fo, L.relu, stream));
+        GWEN_TRY(after());
+        projected = false;
+      }
+      cur = dst;
+      continue;
+    }
+    const int o = resolve_order(L);
     if (o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) {
-      GWEN_TRY(before(GWEN_KIND_LAYER, i, fi, fo));
-      if (!g_rowptr || !g_col || !g_val) return GWEN_EINVAL;
-      GWEN_TRY(gwen_gcn_layer_f32(g_rowptr, g_col, g_val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
-                                  members, N * fi, N * fo, L.relu,
-                                  o == GWEN_ORDER_FUSED_EXACT, stream));
-      GWEN_TRY(after());
+      if (!have_grouped) return GWEN_EINVAL;
+      const bool chain = L.order == GWEN_ORDER_AUTO && !last && shrinking_auto(i + 1) &&
+                         gwen_gcn_chain_supported(fi, fo, layers[i + 1].fout, 0);
+      // a chained kernel stores the NEXT layer's input, never the stack's output
+      float *dst = (last && !chain) ? out : buf[nbuf++ & 1];
+      if (chain) {
+        GWEN_TRY(before(GWEN_KIND_CHAIN, i, fi, layers[i + 1].fout));
+        GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, L.W, layers[i + 1].W, L.bias, dst,
+                                    N, fi, fo, layers[i + 1].fout, 0, L.relu, members, N * fi,
+                                    N * layers[i + 1].fout, stream));
+        GWEN_TRY(after());
+        projected = true;
+      } else {
+        GWEN_TRY(before(GWEN_KIND_LAYER, i, fi, fo));
+        GWEN_TRY(gwen_gcn_layer_f32(g_rowptr, g_col, g_val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
+                                    members, N * fi, N * fo, L.relu, o == GWEN_ORDER_FUSED_EXACT,
+                                    stream));
+        GWEN_TRY(after());
+      }
+      cur = dst;
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
+      float *dst = last ? out : buf[nbuf++ & 1];
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
       GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, stream));
       GWEN_TRY(after());
@@ -110,7 +155,9 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
       GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, tmp, L.bias, dst, N, fo, fo, fo, members,
                                       N * fo, N * fo, L.relu, stream));
       GWEN_TRY(after());
+      cur = dst;
     } else if (o == GWEN_ORDER_AGGREGATE_FIRST) {
+      float *dst = last ? out : buf[nbuf++ & 1];
       GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fi, fi));
       GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, cur, nullptr, tmp, N, fi, fi, fi, members,
                                       N * fi, N * fi, 0, stream));
@@ -118,10 +165,10 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
       GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, stream));
       GWEN_TRY(after());
+      cur = dst;
     } else {
       return GWEN_EINVAL;
     }
-    cur = dst;
   }
 #undef GWEN_TRY
   if (n_launches) *n_launches = nl;

@@ -110,6 +110,27 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     return out
 
 
+def chain(graph: GraphCSR, x: Tensor, w1: Tensor, w2: Optional[Tensor], bias: Optional[Tensor],
+          relu: bool, pre: bool) -> Tensor:
+    """K5.  pre=False: act((A~ x) w1^T + bias) w2^T;  pre=True: act(A~ x + bias) w1^T  (inference only)."""
+    _require(x, "x")
+    x = x.contiguous()
+    m, n, fin = _rows2d(x)
+    f1 = w1.size(0)
+    f2 = 0 if w2 is None else w2.size(0)
+    fw = f2 if f2 else f1
+    out = torch.empty(*x.shape[:-1], fw, dtype=torch.float32, device=x.device)
+    g_rowptr, g_col, g_val = graph.grouped()
+    dev = x.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_chain_f32(
+            _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(w1.contiguous()),
+            None if w2 is None else _ptr(w2.contiguous()), None if bias is None else _ptr(bias.contiguous()),
+            _ptr(out), n, fin, f1, f2, int(pre), int(relu), m, n * fin, n * fw, _stream(dev))
+    _lib.check(rc, "gwen_gcn_chain_f32")
+    return out
+
+
 def _grad_workspace(rows: int, fin: int, fout: int, dev) -> Tensor:
     n = int(_lib.lib().gwen_gcn_grad_workspace_floats(rows, fin, fout))
     return torch.empty(n, dtype=torch.float32, device=dev)

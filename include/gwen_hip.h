@@ -121,13 +121,29 @@ int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, const float *v
 int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
 
 /* ---------------------------------------------------------------------------------------------
+ * K5  K4 with the NEXT layer's projection chained on (A~ is linear, so a layer may be gathered at
+ * min(Fin, Fout); for a shrinking layer its projection must exist before its gather starts):
+ *   pre = 0:  out = act( (A~ x) W1^T + bias ) W2^T     x [.,Fin], W1 [F1,Fin], W2 [F2,F1], F2 < F1
+ *   pre = 1:  out = act( A~ h + bias ) W1^T            h [.,Fin] already projected, bias [Fin], F2 = 0
+ * rowptr/col/val: GROUPED arrays; x, out contiguous rows; widths in {16, 32, 64, 128}; 3xbf16
+ * contraction as K4 (exact = 0).  The re-bracketing changes fp32 rounding order only.
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_chain_supported(int64_t Fin, int64_t F1, int64_t F2, int pre);
+int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
+                       const float *W1, const float *W2, const float *bias, float *out, int64_t N,
+                       int64_t Fin, int64_t F1, int64_t F2, int pre, int relu, int64_t members,
+                       int64_t mstride_x, int64_t mstride_o, gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Whole-stack forward == GNNModel.forward (/root/reference/src/gwen/models_gnn.py:292-303 ->
  * :241-258 -> :135-157, :189-212): every layer of the stack issued back to back from one host
  * call, so the host never limits the device (the reference pays ~15 eager launches per layer).
  *
  * layers (HOST array): per layer W [fout, fin], bias [fout] or NULL (device pointers), relu 0/1 and
- *   order: GWEN_ORDER_AUTO picks K4 when gwen_gcn_layer_supported(fin, fout), otherwise
- *   transform-first (K3 then K2) when fout <= fin, aggregate-first (K2 then K3) when fin < fout.
+ *   order: GWEN_ORDER_AUTO picks K4 when gwen_gcn_layer_supported(fin, fout) -- and chains the next
+ *   layer's projection (K5) when that layer is AUTO too and shrinks, so that it is gathered at its
+ *   narrow width -- otherwise transform-first (K3 then K2) when fout <= fin, aggregate-first (K2
+ *   then K3) when fin < fout.  Explicit orders are taken literally, layer by layer.
  * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4 layers;
  *   may be NULL when no layer resolves to K4).
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
@@ -144,6 +160,7 @@ int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
 #define GWEN_KIND_LINEAR 3      /* K3 */
 #define GWEN_KIND_PROPAGATE 2   /* K2 */
 #define GWEN_KIND_LAYER 4       /* K4 */
+#define GWEN_KIND_CHAIN 5       /* K5: info.fin = gathered width, info.fout = stored width */
 
 typedef struct gwen_layer_desc {
   const float *W;
