@@ -51,9 +51,9 @@ def parse():
     p.add_argument("--reorder", default="morton", choices=["none", "morton"])
     p.add_argument("--order", default="auto", choices=["auto", "unfused"],
                    help="auto: K4 fused layer where the widths allow; unfused: K3 + K2 per layer")
-    p.add_argument("--event-stride", type=int, default=4,
-                   help="record per-kernel hipEvents on every n-th timed step (each record costs "
-                        "the stream a few microseconds, so instrumenting every step would slow the "
+    p.add_argument("--event-stride", type=int, default=20,
+                   help="record per-kernel hipEvents on every n-th timed step (each pair of records "
+                        "opens a ~10 us gap on the stream, so instrumenting every step would slow the "
                         "steps being timed)")
     p.add_argument("--graph", action="store_true",
                    help="replay a captured hipGraph per step instead of issuing the 6 launches from the "
@@ -189,7 +189,9 @@ def main():
         tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
         tag = {"layer": f"k_layer<{fin}, {fout},", "chain": f"k_chain<{fin},", "linear": "k_linear<",
                "propagate": "k_propagate<"}[kind]
-        hits = [v["hbm_bytes_per_launch"] for k_, v in tf.items() if k_.startswith(tag)]
+        hits = [v["hbm_bytes_per_launch"] for k_, v in tf.items()
+                if k_.startswith(tag) and (kind != "chain" or k_.split(",")[1].strip() != "0"
+                                           and fout in (int(k_.split(",")[1]), int(k_.split(",")[2])))]
         if hits and (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1):
             traffic = hits[0]
     except (OSError, KeyError, ValueError):

@@ -221,6 +221,67 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
   }
 }
 
+// Activation-first layer with nothing chained: out = act(A~ h + bias) on the grouped layout (the
+// fma form of K2; K2 itself keeps the rounded-product order that is bit-identical to the CPU path).
+template <int FIN>
+__global__ __launch_bounds__(256) void k_gather(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ bias,
+    float *__restrict__ out, int32_t N, int64_t mstride_x, int64_t mstride_o, int relu) {
+  constexpr int G = FIN / 4, R = 64 / G, BR = 4 * R;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gl = lane % G, gr = lane / G;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nb >> 3, r8 = nb & 7;
+  const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int r = lb * BR + wave * R + gr;
+  const char *xb = reinterpret_cast<const char *>(x + (int64_t)blockIdx.y * mstride_x);
+  float *om = out + (int64_t)blockIdx.y * mstride_o;
+  constexpr uint32_t kRowBytes = FIN * 4;
+  const uint32_t lane_off = gl * 16;
+  const bool ok = r < N;
+  const int32_t ra = rowptr[ok ? r : N], rb = rowptr[ok ? r + 1 : N];
+  int32_t s = rb > ra ? ra : rowptr[N];
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (;;) {
+    const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
+    const int4_u c1 = *reinterpret_cast<const int4_u *>(col + s + 4);
+    const float4_u w0 = *reinterpret_cast<const float4_u *>(val + s);
+    const float4_u w1 = *reinterpret_cast<const float4_u *>(val + s + 4);
+    float4_t v[kBatch];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c0[u] * kRowBytes + lane_off));
+      v[u + 4] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c1[u] * kRowBytes + lane_off));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc = __builtin_elementwise_fma(float4_t{w0[u], w0[u], w0[u], w0[u]}, v[u], acc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc = __builtin_elementwise_fma(float4_t{w1[u], w1[u], w1[u], w1[u]}, v[u + 4], acc);
+    s += kBatch;
+    if (s >= rb) break;
+  }
+  if (bias) acc = acc + *reinterpret_cast<const float4_t *>(bias + gl * 4);
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] < 0.0f ? 0.0f : acc[e];
+  }
+  if (ok) *reinterpret_cast<float4_t *>(om + (int64_t)r * FIN + gl * 4) = acc;
+}
+
+template <int FIN>
+int launch_gather(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
+                  const float *bias, float *out, int64_t N, int64_t members, int64_t msx,
+                  int64_t mso, int relu, hipStream_t st) {
+  constexpr int BR = 4 * (64 / (FIN / 4));
+  dim3 grid((unsigned)((N + BR - 1) / BR), (unsigned)members);
+  k_gather<FIN><<<grid, 256, 0, st>>>(rowptr, col, val, x, bias, out, (int32_t)N, msx, mso, relu);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
 template <int FIN, int F1, int F2, bool PRE>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
            const float *W1, const float *W2, const float *bias, float *out, int64_t N,
@@ -239,6 +300,7 @@ constexpr bool width_ok(int64_t f) { return f == 16 || f == 32 || f == 64 || f =
 }  // namespace
 
 extern "C" int gwen_gcn_chain_supported(int64_t Fin, int64_t F1, int64_t F2, int pre) {
+  if (pre && F1 == 0 && F2 == 0) return width_ok(Fin) ? 1 : 0;      // activation-first, nothing chained
   if (!width_ok(Fin) || !width_ok(F1)) return 0;
   if (pre) return F2 == 0 ? 1 : 0;
   return (width_ok(F2) && F2 < F1) ? 1 : 0;          // chained projection of a SHRINKING next layer
@@ -252,13 +314,21 @@ extern "C" int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, con
   if (N < 0 || members < 0) return GWEN_EINVAL;
   if (!gwen_gcn_chain_supported(Fin, F1, F2, pre)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
-  if (!rowptr || !col || !val || !x || !W1 || !out || x == out || (F2 > 0 && !W2)) return GWEN_EINVAL;
+  if (!rowptr || !col || !val || !x || (F1 > 0 && !W1) || !out || x == out || (F2 > 0 && !W2))
+    return GWEN_EINVAL;
   if (N >= (int64_t(1) << 31) - 1 || members > 65535) return GWEN_ERANGE;
-  if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || !gwen_aligned(W1, 16) ||
+  if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || (W1 && !gwen_aligned(W1, 16)) ||
       (W2 && !gwen_aligned(W2, 16)) || (bias && !gwen_aligned(bias, 16)) || mstride_x % 4)
     return GWEN_EINVAL;
   if (N * Fin * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
+  if (pre && F1 == 0) {
+#define GWEN_G(FI)                                                                                  \
+  if (Fin == FI)                                                                                    \
+    return launch_gather<FI>(rowptr, col, val, x, bias, out, N, members, mstride_x, mstride_o, relu, st)
+    GWEN_G(16); GWEN_G(32); GWEN_G(64); GWEN_G(128);
+#undef GWEN_G
+  }
 #define GWEN_P(FI, FA)                                                                              \
   if (pre && Fin == FI && F1 == FA)                                                                 \
     return launch<FI, FA, 0, true>(rowptr, col, val, x, W1, W2, bias, out, N, members, mstride_x,   \

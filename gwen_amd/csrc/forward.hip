@@ -114,6 +114,12 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
                                     N * layers[i + 1].fout, stream));
         GWEN_TRY(after());
         projected = true;
+      } else if (have_grouped && gwen_gcn_chain_supported(fo, 0, 0, 1)) {
+        GWEN_TRY(before(GWEN_KIND_CHAIN, i, fo, fo));
+        GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, nullptr, nullptr, L.bias, dst, N,
+                                    fo, 0, 0, 1, L.relu, members, N * fo, N * fo, stream));
+        GWEN_TRY(after());
+        projected = false;
       } else {
         GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fo, fo));
         GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, cur, L.bias, dst, N, fo, fo, fo, members,

@@ -293,6 +293,25 @@ def test_chained_kernel_vs_oracle(ga, cref, case, fin, f1, f2, pre):
     assert rel_err(got, want) <= 3e-5
 
 
+@pytest.mark.parametrize("F", [16, 32, 64, 128])
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_grouped_gather_kernel(ga, cref, case, F):
+    """K5 with nothing chained (activation-first propagate on the grouped layout) == K2 to rounding."""
+    from gwen_amd import ops, _lib
+    from gwen_amd.graph import _ptr, _stream
+    name, n, ei = case
+    g = ga.prepare_graph(ei.to(DEV), n)
+    h = torch.randn(n, F, generator=torch.Generator().manual_seed(SEED)).to(DEV)
+    b = (torch.randn(F, generator=torch.Generator().manual_seed(SEED + 1)) * 0.1).to(DEV)
+    want = ops.propagate(g, h, b, True)
+    out = torch.empty_like(h)
+    gr, gc, gv = g.grouped()
+    rc = _lib.lib().gwen_gcn_chain_f32(_ptr(gr), _ptr(gc), _ptr(gv), _ptr(h), None, None, _ptr(b), _ptr(out),
+                                       n, F, 0, 0, 1, 1, 1, n * F, n * F, _stream(h.device))
+    assert rc == 0
+    assert rel_err(out, want) <= 2e-6
+
+
 @pytest.mark.parametrize("members", [1, 3])
 @pytest.mark.parametrize("C,H", [(64, 64), (8, 16), (20, 48), (16, 256), (128, 128), (32, 64)])
 def test_stack_forward_equals_layer_by_layer(ga, members, C, H):
