@@ -155,7 +155,7 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
       float *dst = last ? out : buf[nbuf++ & 1];
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
-      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, stream));
+      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, L.order != GWEN_ORDER_AUTO, stream));
       GWEN_TRY(after());
       GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fo, fo));
       GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, tmp, L.bias, dst, N, fo, fo, fo, members,
@@ -169,7 +169,7 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
                                       N * fi, N * fi, 0, stream));
       GWEN_TRY(after());
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
-      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, stream));
+      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, L.order != GWEN_ORDER_AUTO, stream));
       GWEN_TRY(after());
       cur = dst;
     } else {

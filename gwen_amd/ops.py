@@ -57,8 +57,11 @@ def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: b
     return out
 
 
-def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False) -> Tensor:
-    """K3: act(x @ weight^T + bias) on the fp32 MFMA; x [..., Fin], weight [Fout, Fin]."""
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+           exact: bool = True) -> Tensor:
+    """K3: act(x @ weight^T + bias); x [..., Fin], weight [Fout, Fin].  ``exact=True``: fp32-input MFMA
+    (a k-ordered fp32 fmaf chain, the default of the per-layer/autograd path); ``exact=False``: 3xbf16
+    split contraction with fp32 accumulation (what the stack launcher uses for AUTO layers)."""
     _require(x, "x")
     _require(weight, "weight")
     x = x.contiguous()
@@ -74,7 +77,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool 
     dev = x.device
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_linear_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), rows, fin,
-                                            fout, fin, fout, int(relu), _stream(dev))
+                                            fout, fin, fout, int(relu), int(exact), _stream(dev))
     _lib.check(rc, "gwen_gcn_linear_f32")
     return out
 

@@ -94,11 +94,12 @@ int gwen_gcn_propagate_f32(const int32_t *rowptr, const int32_t *col, const floa
 /* ---------------------------------------------------------------------------------------------
  * K3  dense projection == GCNConv.lin (PyG Linear(Fin, Fout, bias=False)):  h = x @ W^T.
  * x [rows, Fin] (row stride ldx), W [Fout, Fin] contiguous (lin.weight), h [rows, Fout]
- * (row stride ldh).  fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate: exact fp32 fmaf chain.
- * Optional epilogue: + bias[Fout] (NULL = none), ReLU.
+ * (row stride ldh).  Optional epilogue: + bias[Fout] (NULL = none), ReLU.
+ * exact = 0: 3xbf16 split contraction, fp32 accumulate (as K4; < 2^-15 relative per product);
+ * exact = 1: fp32-input MFMA (v_mfma_f32_32x32x2_f32), bit-identical to a k-ordered fp32 fmaf chain.
  * ------------------------------------------------------------------------------------------- */
 int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows,
-                        int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldh, int relu,
+                        int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldh, int relu, int exact,
                         gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

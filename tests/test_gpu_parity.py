@@ -164,6 +164,10 @@ def test_linear(ga, cref, rows, fin, fout):
     got2 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True).cpu()
     ref2 = torch.relu(torch.from_numpy(chain) + b)
     assert torch.equal(got2, ref2)
+    # 3xbf16 split variant: fp32-class accuracy, not bitwise
+    got3 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, exact=False).cpu()
+    ref3 = torch.relu(ref64 + b.double())
+    assert rel_err(got3, ref3) <= 2e-5
 
 
 # ------------------------------------------------------------------------------------------------
