@@ -7,7 +7,7 @@
 //
 // Shape (wave64): many SHORT blocks -- K2's shape -- so that the waves sharing a SIMD are in
 // different phases (gather / MFMA / store) and the per-wave critical path is one or two gathers:
-//   block = NWB waves (4, or 8 when Fout = 128) = BR consecutive destination rows (>= 32);
+//   block = NWB waves (one per 16-column output tile, at least 4) = BR consecutive destination rows;
 //   phase 1  every wave gathers R = 64/(Fin/4) rows per pass (Fin/4 lanes per row, 16-B loads, the 8
 //            entries of a group in flight together) from the GROUPED layout (rows padded to whole
 //            groups of 8 with weight-0 entries, null group for absent rows), so every load in the
@@ -56,7 +56,7 @@ template <int FIN, int FOUT, bool SPLIT, int BRMIN = 32>
 struct Cfg {
   static constexpr int G = FIN / 4, R = 64 / G;            // lanes per gathered row, rows per wave pass
   static constexpr int NJ = FOUT / 16;                     // 16-column output tiles
-  static constexpr int NWB = NJ > 4 ? 8 : 4;               // waves per block
+  static constexpr int NWB = NJ > 8 ? 16 : (NJ > 4 ? 8 : 4);   // waves per block: one per column tile
   static constexpr int RB = NWB * R;                       // rows gathered per block pass
   static constexpr int BR = RB > BRMIN ? RB : BRMIN;       // rows per block
   static constexpr int NP = BR / RB;                       // gather passes per wave
@@ -72,7 +72,7 @@ struct Cfg {
 };
 
 template <int FIN, int FOUT, bool SPLIT, int BRMIN>
-__global__ __launch_bounds__((FOUT > 64 ? 512 : 256)) void k_layer(
+__global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void k_layer(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int64_t ldo,
@@ -210,7 +210,7 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st) {
   // rows per block: enough that W (read once per block) stays a small fraction of the gathered bytes
-  constexpr int BRMIN = FIN >= 128 ? 128 : 64;
+  constexpr int BRMIN = FIN == 128 ? 128 : 64;     // 256: 64 rows keep two blocks per CU in LDS
   using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
   const int64_t blocks = (N + C::BR - 1) / C::BR;
   dim3 grid((unsigned)blocks, (unsigned)members);
@@ -220,7 +220,7 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
   return GWEN_OK;
 }
 
-constexpr bool width_ok(int64_t f) { return f == 16 || f == 32 || f == 64 || f == 128; }
+constexpr bool width_ok(int64_t f) { return f == 16 || f == 32 || f == 64 || f == 128 || f == 256; }
 
 }  // namespace
 
@@ -253,6 +253,8 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
   GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);
   GWEN_L(64, 16); GWEN_L(64, 32); GWEN_L(64, 64); GWEN_L(64, 128);
   GWEN_L(128, 16); GWEN_L(128, 32); GWEN_L(128, 64); GWEN_L(128, 128);
+  GWEN_L(16, 256); GWEN_L(32, 256); GWEN_L(64, 256); GWEN_L(128, 256);
+  GWEN_L(256, 16); GWEN_L(256, 32); GWEN_L(256, 64); GWEN_L(256, 128); GWEN_L(256, 256);
 #undef GWEN_L
   return GWEN_EINVAL;
 }

@@ -142,9 +142,12 @@ def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tens
     status = torch.empty(2, dtype=torch.int32, device=dev)
     ws = _alloc_workspace(n, e, dev)
     loops = bool(add_self_loops and normalize)      # loops are completed inside gcn_norm only
+    # torch-geometric 2.3.x completes the self-loops BEFORE it materialises unit weights, so without
+    # explicit edge weights every loop gets weight 1 and `improved` (fill 2) only acts on weighted graphs
+    fill = 2.0 if (improved and ew is not None) else 1.0
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_prep(
-            _ptr(ei), _ptr(ew), n, e, int(loops), 2.0 if improved else 1.0, int(normalize),
+            _ptr(ei), _ptr(ew), n, e, int(loops), fill, int(normalize),
             _ptr(rowptr), _ptr(col), _ptr(val), _ptr(eid), _ptr(dis), _ptr(status), _ptr(ws),
             ws.numel(), _stream(dev))
     _lib.check(rc, "gwen_gcn_prep")

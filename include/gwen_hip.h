@@ -112,8 +112,8 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
  * exact = 1: fp32-input MFMA, bit-exact fp32 fmaf chains (about 1.3x slower at 64 -> 64).
  * rowptr/col/val here are the GROUPED arrays of gwen_gcn_group8() (rows in whole groups of 8, null
  * group at rowptr[N]); x rows must be contiguous (ldx == Fin) and N * Fin * 4 < 2^32.
- * Supported widths: Fin, Fout in {16, 32, 64, 128} with W and the wave tiles fitting 160 KiB of LDS
- * (gwen_gcn_layer_supported() says; otherwise GWEN_EINVAL: use K3 + K2).  Same alignment rules as K2.
+ * Supported widths: Fin, Fout in {16, 32, 64, 128, 256} (gwen_gcn_layer_supported() says; otherwise
+ * GWEN_EINVAL: use K3 + K2).  Same alignment rules as K2.
  * ------------------------------------------------------------------------------------------- */
 int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
                        const float *W, const float *bias, float *out, int64_t N, int64_t Fin,

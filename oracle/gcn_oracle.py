@@ -69,7 +69,11 @@ def gcn_norm(
     add_self_loops: bool = True,
     dtype: torch.dtype = torch.float32,
 ) -> Tuple[Tensor, Tensor]:
-    """Symmetric normalisation  w~_e = d^-1/2[src] * w_e * d^-1/2[dst],  d = in-degree incl. loop."""
+    """Symmetric normalisation  w~_e = d^-1/2[src] * w_e * d^-1/2[dst],  d = in-degree incl. loop.
+
+    As in torch-geometric 2.3.x the self-loops are completed BEFORE unit weights are materialised, so
+    without explicit edge weights every loop weighs 1 and ``improved`` (fill 2) only acts on weighted
+    graphs (restated from the library's behaviour; the reference never sets ``improved``)."""
     fill = 2.0 if improved else 1.0
     if add_self_loops:
         edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill, num_nodes)

@@ -241,7 +241,8 @@ def test_model_members_axis(ga):
 # K4 fused layer and the whole-stack launcher
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fin,fout", [(16, 16), (16, 32), (32, 16), (64, 64), (64, 32), (32, 64),
-                                      (128, 64), (64, 128), (128, 128), (16, 128)])
+                                      (128, 64), (64, 128), (128, 128), (16, 128), (256, 256), (256, 64),
+                                      (32, 256)])
 @pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_fused_layer_vs_oracle(ga, cref, case, fin, fout):
     from gwen_amd import ops
@@ -264,7 +265,7 @@ def test_fused_layer_vs_oracle(ga, cref, case, fin, fout):
 
 def test_fused_layer_unsupported_widths_are_refused(ga):
     from gwen_amd import ops, _lib
-    assert not ops.layer_supported(8, 8) and not ops.layer_supported(256, 256)
+    assert not ops.layer_supported(8, 8) and not ops.layer_supported(512, 512)
     assert not ops.layer_supported(24, 64)
     g = ga.prepare_graph(CASES[5][2].to(DEV), 3)
     with pytest.raises(_lib.GwenHipError):
