@@ -99,38 +99,59 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int SBM = 128, SBN = 128, SBK = 32, SPB = 48;
 
+// One thread's share of a 128-row x 32-deep fp32 slab: 4 x 16 B, rows idx/8, k (idx%8)*4.
 template <bool VEC>
-__device__ inline void stage_split(const float *__restrict__ g, int64_t ld, int64_t row0,
-                                   int64_t nrows, int k0, int K, __bf16 *__restrict__ hi,
-                                   __bf16 *__restrict__ lo) {
-  // [128][SPB] hi/lo <- g[row0 .. +128)[k0 .. k0+32), zero-filled outside
-  for (int idx = threadIdx.x; idx < 128 * (SBK / 4); idx += kThreads) {
-    const int r = idx / (SBK / 4), kq = (idx % (SBK / 4)) * 4;
-    float4_t v = {0.f, 0.f, 0.f, 0.f};
-    const int64_t gr = row0 + r;
-    if (gr < nrows) {
-      const float *p = g + gr * ld + k0 + kq;
-      if (VEC && k0 + kq + 3 < K) {
-        v = *reinterpret_cast<const float4_t *>(p);
-      } else {
+__device__ inline void slab_load(const float *__restrict__ g, int64_t ld, int64_t row0,
+                                 int64_t nrows, int k0, int K, float4_t (&v)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (k0 + kq + i < K) v[i] = p[i];
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * kThreads;
+    const int r = idx >> 3, kq = (idx & 7) * 4;
+    const int64_t gr = row0 + r;
+    if constexpr (VEC) {
+      // unconditional 16-B load from a clamped (always valid) address, zeroed by select: a load under
+      // a per-lane condition would be branched around and followed by vmcnt(0) (K % 4 == 0 here, so a
+      // quad is inside or outside K as a whole)
+      const bool ok = gr < nrows && k0 + kq < K;
+      const int64_t cr = gr < nrows ? gr : nrows - 1;
+      const int ck = k0 + kq < K ? k0 + kq : 0;
+      const float4_t t = *reinterpret_cast<const float4_t *>(g + cr * ld + ck);
+      v[i] = ok ? t : float4_t{0.f, 0.f, 0.f, 0.f};
+    } else {
+      v[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+      if (gr < nrows) {
+        const float *p = g + gr * ld + k0 + kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k0 + kq + e < K) v[i][e] = p[e];
       }
     }
+  }
+}
+
+// split the slab share into bf16 hi/lo and park it in the LDS images [128][SPB]
+__device__ inline void slab_store(const float4_t (&v)[4], __bf16 *__restrict__ hi,
+                                  __bf16 *__restrict__ lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * kThreads;
+    const int r = idx >> 3, kq = (idx & 7) * 4;
     bf16x4 h4, l4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const __bf16 h = (__bf16)v[i];
-      h4[i] = h;
-      l4[i] = (__bf16)(v[i] - (float)h);
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h = (__bf16)v[i][e];
+      h4[e] = h;
+      l4[e] = (__bf16)(v[i][e] - (float)h);
     }
     *reinterpret_cast<bf16x4 *>(hi + r * SPB + kq) = h4;
     *reinterpret_cast<bf16x4 *>(lo + r * SPB + kq) = l4;
   }
 }
 
-template <bool VEC>
+// NCT = 16-column tiles per block (8: 128 columns; 4: 64 columns for narrow outputs).
+// The next slab's global loads are issued before the current slab's MFMAs and parked in LDS after
+// them, so their latency hides under the matrix work instead of standing in front of it.
+template <bool VEC, int NCT>
 __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restrict__ x,
                                                            const float *__restrict__ W,
                                                            const float *__restrict__ bias,
@@ -142,18 +163,26 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mi = lane & 15, mh = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * SBM;
-  const int col0 = blockIdx.y * SBN;
+  const int col0 = blockIdx.y * (NCT * 16);
 
-  f32x4 acc[2][8];
+  f32x4 acc[2][NCT];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float4_t pa[4], pb[4];
+  slab_load<VEC>(x, ldx, row0, rows, 0, Fin, pa);
+  slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout), 0, Fin, pb);
+  slab_store(pa, ahi, alo);
+  slab_store(pb, bhi, blo);
+  __syncthreads();
   for (int k0 = 0; k0 < Fin; k0 += SBK) {
-    stage_split<VEC>(x, ldx, row0, rows, k0, Fin, ahi, alo);
-    stage_split<VEC>(W, Fin, col0, Fout, k0, Fin, bhi, blo);
-    __syncthreads();
+    const bool more = k0 + SBK < Fin;
+    // issued unconditionally (past the last slab the loads are clamped and their result unused)
+    slab_load<VEC>(x, ldx, row0, rows, k0 + SBK, Fin, pa);
+    slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout),
+                   k0 + SBK, Fin, pb);
     bf16x8 fah[2], fal[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
       fal[rt] = *reinterpret_cast<const bf16x8 *>(alo + off);
     }
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
       const int off = (ct * 16 + mi) * SPB + 8 * mh;
       const bf16x8 fbh = *reinterpret_cast<const bf16x8 *>(bhi + off);
       const bf16x8 fbl = *reinterpret_cast<const bf16x8 *>(blo + off);
@@ -173,12 +202,17 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[rt], fbh, acc[rt][ct], 0, 0, 0);
       }
     }
-    __syncthreads();
+    __syncthreads();                       // every wave is done reading this slab
+    if (more) {
+      slab_store(pa, ahi, alo);
+      slab_store(pb, bhi, blo);
+      __syncthreads();
+    }
   }
 
   // D[row = 4*mh + t][col = mi] of each 16x16 tile
 #pragma unroll
-  for (int ct = 0; ct < 8; ++ct) {
+  for (int ct = 0; ct < NCT; ++ct) {
     const int c = col0 + ct * 16 + mi;
     if (c >= Fout) continue;
     const float bv = bias ? bias[c] : 0.0f;
@@ -206,14 +240,17 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
   if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
   const bool vec = Fin % 4 == 0 && ldx % 4 == 0 && gwen_aligned(x, 16) && gwen_aligned(W, 16);
-  if (!exact) {
-    const int64_t sx = (rows + SBM - 1) / SBM, sy = (Fout + SBN - 1) / SBN;
+  if (!exact && Fin > 0) {      // Fin == 0: nothing to contract, the exact kernel writes act(bias)
+    const int bn = Fout <= 64 ? 64 : SBN;           // narrow outputs: 64-column blocks, no empty tiles
+    const int64_t sx = (rows + SBM - 1) / SBM, sy = (Fout + bn - 1) / bn;
     if (sx > 0x7fffffffLL || sy > 65535) return GWEN_ERANGE;
     dim3 sgrid((unsigned)sx, (unsigned)sy);
-    if (vec)
-      k_linear_split<true><<<sgrid, kThreads, 0, st>>>(x, W, bias, h, rows, (int)Fin, (int)Fout, ldx, ldh, relu);
-    else
-      k_linear_split<false><<<sgrid, kThreads, 0, st>>>(x, W, bias, h, rows, (int)Fin, (int)Fout, ldx, ldh, relu);
+#define GWEN_LS(V, T)                                                                             \
+  k_linear_split<V, T><<<sgrid, kThreads, 0, st>>>(x, W, bias, h, rows, (int)Fin, (int)Fout, ldx,  \
+                                                   ldh, relu)
+    if (vec) { if (bn == 64) GWEN_LS(true, 4); else GWEN_LS(true, 8); }
+    else     { if (bn == 64) GWEN_LS(false, 4); else GWEN_LS(false, 8); }
+#undef GWEN_LS
     GWEN_LAUNCH_CHECK();
     return GWEN_OK;
   }
