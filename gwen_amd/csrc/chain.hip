@@ -102,7 +102,7 @@ struct Cfg {
   static_assert(NWB % NJ1 == 0 && (F2 == 0 || NWB % NJ2 == 0), "waves must tile the columns");
 };
 
-template <int FIN, int F1, int F2, bool PRE>
+template <int FIN, int F1, int F2, bool PRE, bool UNI>
 __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W1,
@@ -125,7 +125,7 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
   float *om = out + (int64_t)blockIdx.y * mstride_o;
   constexpr uint32_t kRowBytes = FIN * 4;
   const uint32_t lane_off = gl * 16;
-  const int32_t null_off = rowptr[N];
+  const int32_t null_off = UNI ? 8 * N : rowptr[N];
 
   // weights of both contractions for this wave's column tiles, issued before the gathers
   const int j1 = wave % C::NJ1;
@@ -145,8 +145,15 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
     const int lr = p * C::RB + wave * C::R + gr;
     const int r = b0 + lr;
     const bool ok = r < N;
-    const int32_t ra = rowptr[ok ? r : N], rb = rowptr[ok ? r + 1 : N];
-    int32_t s = rb > ra ? ra : null_off;
+    int32_t s, rb;
+    if constexpr (UNI) {          // every row is exactly one group: no rowptr lookup, no loop
+      s = ok ? 8 * r : 8 * N;
+      rb = 0;
+    } else {
+      const int32_t ra = rowptr[ok ? r : N];
+      rb = rowptr[ok ? r + 1 : N];
+      s = rb > ra ? ra : null_off;
+    }
     float4_t acc = {0.f, 0.f, 0.f, 0.f};
     for (;;) {
       const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
@@ -223,7 +230,7 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
 
 // Activation-first layer with nothing chained: out = act(A~ h + bias) on the grouped layout (the
 // fma form of K2; K2 itself keeps the rounded-product order that is bit-identical to the CPU path).
-template <int FIN>
+template <int FIN, bool UNI>
 __global__ __launch_bounds__(256) void k_gather(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ bias,
@@ -240,8 +247,15 @@ __global__ __launch_bounds__(256) void k_gather(
   constexpr uint32_t kRowBytes = FIN * 4;
   const uint32_t lane_off = gl * 16;
   const bool ok = r < N;
-  const int32_t ra = rowptr[ok ? r : N], rb = rowptr[ok ? r + 1 : N];
-  int32_t s = rb > ra ? ra : rowptr[N];
+  int32_t s, rb;
+  if constexpr (UNI) {
+    s = ok ? 8 * r : 8 * N;
+    rb = 0;
+  } else {
+    const int32_t ra = rowptr[ok ? r : N];
+    rb = rowptr[ok ? r + 1 : N];
+    s = rb > ra ? ra : rowptr[N];
+  }
   float4_t acc = {0.f, 0.f, 0.f, 0.f};
   for (;;) {
     const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
@@ -277,7 +291,10 @@ int launch_gather(const int32_t *rowptr, const int32_t *col, const float *val, c
                   int64_t mso, int relu, hipStream_t st) {
   constexpr int BR = 4 * (64 / (FIN / 4));
   dim3 grid((unsigned)((N + BR - 1) / BR), (unsigned)members);
-  k_gather<FIN><<<grid, 256, 0, st>>>(rowptr, col, val, x, bias, out, (int32_t)N, msx, mso, relu);
+  if (!rowptr)
+    k_gather<FIN, true><<<grid, 256, 0, st>>>(rowptr, col, val, x, bias, out, (int32_t)N, msx, mso, relu);
+  else
+    k_gather<FIN, false><<<grid, 256, 0, st>>>(rowptr, col, val, x, bias, out, (int32_t)N, msx, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -289,8 +306,12 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
   using C = Cfg<FIN, F1, F2, PRE>;
   const int64_t blocks = (N + C::BR - 1) / C::BR;
   dim3 grid((unsigned)blocks, (unsigned)members);
-  k_chain<FIN, F1, F2, PRE><<<grid, C::NWB * 64, 0, st>>>(rowptr, col, val, x, W1, W2, bias, out,
-                                                            (int32_t)N, msx, mso, relu);
+  if (!rowptr)
+    k_chain<FIN, F1, F2, PRE, true><<<grid, C::NWB * 64, 0, st>>>(rowptr, col, val, x, W1, W2, bias, out,
+                                                                  (int32_t)N, msx, mso, relu);
+  else
+    k_chain<FIN, F1, F2, PRE, false><<<grid, C::NWB * 64, 0, st>>>(rowptr, col, val, x, W1, W2, bias,
+                                                                   out, (int32_t)N, msx, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -314,9 +335,9 @@ extern "C" int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, con
   if (N < 0 || members < 0) return GWEN_EINVAL;
   if (!gwen_gcn_chain_supported(Fin, F1, F2, pre)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
-  if (!rowptr || !col || !val || !x || (F1 > 0 && !W1) || !out || x == out || (F2 > 0 && !W2))
-    return GWEN_EINVAL;
-  if (N >= (int64_t(1) << 31) - 1 || members > 65535) return GWEN_ERANGE;
+  if (!col || !val || !x || (F1 > 0 && !W1) || !out || x == out || (F2 > 0 && !W2))
+    return GWEN_EINVAL;                                    // rowptr NULL = uniform layout
+  if (N >= (int64_t(1) << 28) || members > 65535) return GWEN_ERANGE;
   if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || (W1 && !gwen_aligned(W1, 16)) ||
       (W2 && !gwen_aligned(W2, 16)) || (bias && !gwen_aligned(bias, 16)) || mstride_x % 4)
     return GWEN_EINVAL;

@@ -93,7 +93,7 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
   auto shrinking_auto = [&](int32_t i) {
     return i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin;
   };
-  const bool have_grouped = g_rowptr && g_col && g_val;
+  const bool have_grouped = g_col && g_val;          // g_rowptr NULL = uniform layout
 
   const float *cur = x;
   bool projected = false;          // cur holds h_i = a_i W_i^T (layer i's bias/ReLU still pending)

@@ -71,7 +71,7 @@ struct Cfg {
   static_assert(NWB % NJ == 0, "waves must tile the output columns");
 };
 
-template <int FIN, int FOUT, bool SPLIT, int BRMIN>
+template <int FIN, int FOUT, bool SPLIT, int BRMIN, bool UNI = false>
 __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void k_layer(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W,
@@ -96,7 +96,7 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   float *om = out + (int64_t)blockIdx.y * mstride_o;
   constexpr uint32_t kRowBytes = FIN * 4;                  // x rows are contiguous (ldx == Fin)
   const uint32_t lane_off = gl * 16;
-  const int32_t null_off = rowptr[N];
+  const int32_t null_off = UNI ? 8 * N : rowptr[N];
 
   // ---- this wave's B fragments (its 16 output columns of W^T), issued before the gathers ---------
   const int j = wave % C::NJ;
@@ -129,8 +129,15 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
     const int lr = p * C::RB + wave * C::R + gr;
     const int r = b0 + lr;
     const bool ok = r < N;
-    const int32_t ra = rowptr[ok ? r : N], rb = rowptr[ok ? r + 1 : N];
-    int32_t s = rb > ra ? ra : null_off;
+    int32_t s, rb;
+    if constexpr (UNI) {          // every row is exactly one group: no rowptr lookup, no loop
+      s = ok ? 8 * r : 8 * N;
+      rb = 0;
+    } else {
+      const int32_t ra = rowptr[ok ? r : N];
+      rb = rowptr[ok ? r + 1 : N];
+      s = rb > ra ? ra : null_off;
+    }
     float4_t acc = {0.f, 0.f, 0.f, 0.f};
     for (;;) {
       const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
@@ -214,8 +221,12 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
   using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
   const int64_t blocks = (N + C::BR - 1) / C::BR;
   dim3 grid((unsigned)blocks, (unsigned)members);
-  k_layer<FIN, FOUT, SPLIT, BRMIN><<<grid, C::NWB * 64, 0, st>>>(rowptr, col, val, x, W, bias, out,
-                                                                  (int32_t)N, ldo, msx, mso, relu);
+  if (!rowptr)      // uniform layout: row r is the group at 8 r
+    k_layer<FIN, FOUT, SPLIT, BRMIN, true><<<grid, C::NWB * 64, 0, st>>>(
+        rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu);
+  else
+    k_layer<FIN, FOUT, SPLIT, BRMIN, false><<<grid, C::NWB * 64, 0, st>>>(
+        rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -236,8 +247,8 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
   if (N < 0 || members < 0 || ldx < Fin || ldo < Fout) return GWEN_EINVAL;
   if (!gwen_gcn_layer_supported(Fin, Fout)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
-  if (!rowptr || !col || !val || !x || !W || !out || x == out) return GWEN_EINVAL;
-  if (N >= (int64_t(1) << 31) - 1 || members > 65535) return GWEN_ERANGE;
+  if (!col || !val || !x || !W || !out || x == out) return GWEN_EINVAL;   // rowptr NULL = uniform
+  if (N >= (int64_t(1) << 28) || members > 65535) return GWEN_ERANGE;     // 8 N must fit int32
   if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || !gwen_aligned(W, 16) || ldx != Fin ||
       mstride_x % 4)
     return GWEN_EINVAL;                       // x rows must be contiguous (32-bit row offsets)

@@ -166,11 +166,16 @@ __global__ void k_tfill(const uint64_t *__restrict__ ks, const int32_t *__restri
 }
 
 // ---- grouped layout (rows padded to whole groups of 8 entries) ------------------------------
-__global__ void k_glen(const int32_t *__restrict__ rowptr, int64_t N, int32_t *__restrict__ glen) {
+__global__ void k_glen(const int32_t *__restrict__ rowptr, int64_t N, int32_t *__restrict__ glen,
+                       int32_t *__restrict__ uniform) {
   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r > N) return;
-  glen[r] = r < N ? ((rowptr[r + 1] - rowptr[r] + 7) & ~7) : 0;
+  const int32_t g = r < N ? ((rowptr[r + 1] - rowptr[r] + 7) & ~7) : 0;
+  glen[r] = g;
+  if (uniform && r < N && g != 8) atomicAnd(uniform, 0);     // some row is not exactly one group
 }
+
+__global__ void k_set1(int32_t *p) { *p = 1; }
 
 // 8 lanes per row copy its entries and append the padding (weight 0, column of the row's first
 // entry: a row that is already part of the sum); lane group N writes the all-zero null group.
@@ -328,8 +333,8 @@ extern "C" int64_t gwen_gcn_group8_capacity(int64_t N, int64_t cap) {
 
 extern "C" int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const float *val,
                                int64_t N, int64_t cap, int32_t *g_rowptr, int32_t *g_col,
-                               float *g_val, void *workspace, size_t workspace_bytes,
-                               gwen_stream_t stream_) {
+                               float *g_val, int32_t *uniform, void *workspace,
+                               size_t workspace_bytes, gwen_stream_t stream_) {
   if (N < 0 || cap < 0 || !rowptr || !g_rowptr || !g_col || !g_val) return GWEN_EINVAL;
   if (cap > 0 && (!col || !val)) return GWEN_EINVAL;
   if (cap + 7 * N + 8 >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
@@ -341,7 +346,11 @@ extern "C" int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const 
   if (!workspace || workspace_bytes < glen_bytes + tb) return GWEN_ENOSPACE;
   int32_t *glen = static_cast<int32_t *>(workspace);
   void *temp = static_cast<char *>(workspace) + glen_bytes;
-  k_glen<<<blocks_for(N + 1), kThreads, 0, stream>>>(rowptr, N, glen);
+  if (uniform) {
+    k_set1<<<1, 1, 0, stream>>>(uniform);
+    GWEN_LAUNCH_CHECK();
+  }
+  k_glen<<<blocks_for(N + 1), kThreads, 0, stream>>>(rowptr, N, glen, uniform);
   GWEN_LAUNCH_CHECK();
   GWEN_HIP_CHECK(rocprim::exclusive_scan(temp, tb, glen, g_rowptr, 0, (size_t)(N + 1),
                                          rocprim::plus<int32_t>(), stream));

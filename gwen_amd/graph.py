@@ -44,7 +44,7 @@ class GraphCSR:
     status: Tensor                 # int32 [2]     [bad-index flag, E']
     _workspace: Optional[Tensor] = field(default=None, repr=False)
     _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
-    _grouped: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
+    _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -54,8 +54,9 @@ class GraphCSR:
         """Number of stored entries E' (synchronises)."""
         return int(self.status[1].item())
 
-    def grouped(self) -> Tuple[Tensor, Tensor, Tensor]:
-        """Rows padded to whole 8-entry groups (rowptr, col, val) for K4; built on first use."""
+    def grouped(self) -> Tuple[Optional[Tensor], Tensor, Tensor]:
+        """Rows padded to whole 8-entry groups (rowptr, col, val) for K4/K5; built on first use.
+        ``rowptr`` is None for a uniform layout (every row exactly one group: offset = 8 * row)."""
         if self._grouped is None:
             self._grouped = _grouped_impl(self)
         return self._grouped
@@ -87,12 +88,17 @@ def _grouped_impl(g: "GraphCSR") -> Tuple[Tensor, Tensor, Tensor]:
     g_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     g_col = torch.empty(gcap, dtype=torch.int32, device=dev)
     g_val = torch.empty(gcap, dtype=torch.float32, device=dev)
+    uniform = torch.empty(1, dtype=torch.int32, device=dev)
     ws = g._workspace if g._workspace is not None else _alloc_workspace(n, g.num_edges, dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_group8(_ptr(g.rowptr), _ptr(g.col), _ptr(g.val), n, cap,
-                                        _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(ws),
-                                        ws.numel(), _stream(dev))
+                                        _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(uniform),
+                                        _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gwen_gcn_group8")
+    # uniform layout (every row exactly one group, e.g. bounded-degree meshes): the kernels take
+    # rowptr = NULL and compute the group offset 8 r themselves; one flag read-back, once per graph
+    if n > 0 and int(uniform.item()) == 1 and n < (1 << 28):
+        return None, g_col, g_val
     return g_rowptr, g_col, g_val
 
 

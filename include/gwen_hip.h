@@ -70,11 +70,14 @@ int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, const float *v
  * indices and weights as aligned 32-byte groups and needs no per-entry bounds logic.
  *   g_rowptr int32 [N+1] (entry offsets, multiples of 8), g_col / g_val [gwen_gcn_group8_capacity()],
  *   followed at g_rowptr[N] by one all-zero "null group" (col 0, weight 0).
+ * uniform (int32 [1], may be NULL) is set to 1 when EVERY row is exactly one group (bounded-degree
+ *   meshes: 1 <= entries <= 8), i.e. g_rowptr[r] == 8 r.  K4/K5 then accept rowptr == NULL and skip the
+ *   row-pointer lookup (one dependent load less per gathered row).
  * workspace: as for gwen_gcn_prep. */
 int64_t gwen_gcn_group8_capacity(int64_t N, int64_t cap);
 int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
-                    int64_t cap, int32_t *g_rowptr, int32_t *g_col, float *g_val, void *workspace,
-                    size_t workspace_bytes, gwen_stream_t stream);
+                    int64_t cap, int32_t *g_rowptr, int32_t *g_col, float *g_val, int32_t *uniform,
+                    void *workspace, size_t workspace_bytes, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  fused propagate == MessagePassing.propagate (message w~ * x_j, aggregate add at target)
@@ -111,7 +114,7 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
  *   relative per product, 8e-6 measured on the 6-layer model against a 1e-4 tolerance);
  * exact = 1: fp32-input MFMA, bit-exact fp32 fmaf chains (about 1.3x slower at 64 -> 64).
  * rowptr/col/val here are the GROUPED arrays of gwen_gcn_group8() (rows in whole groups of 8, null
- * group at rowptr[N]); x rows must be contiguous (ldx == Fin) and N * Fin * 4 < 2^32.
+ * group at rowptr[N]; rowptr may be NULL for a uniform layout, see gwen_gcn_group8); x rows must be contiguous (ldx == Fin) and N * Fin * 4 < 2^32.
  * Supported widths: Fin, Fout in {16, 32, 64, 128, 256} (gwen_gcn_layer_supported() says; otherwise
  * GWEN_EINVAL: use K3 + K2).  Same alignment rules as K2.
  * ------------------------------------------------------------------------------------------- */
@@ -126,7 +129,7 @@ int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
  * min(Fin, Fout); for a shrinking layer its projection must exist before its gather starts):
  *   pre = 0:  out = act( (A~ x) W1^T + bias ) W2^T     x [.,Fin], W1 [F1,Fin], W2 [F2,F1], F2 < F1
  *   pre = 1:  out = act( A~ h + bias ) W1^T            h [.,Fin] already projected, bias [Fin], F2 = 0
- * rowptr/col/val: GROUPED arrays; x, out contiguous rows; widths in {16, 32, 64, 128}; 3xbf16
+ * rowptr/col/val: GROUPED arrays (rowptr NULL = uniform layout); x, out contiguous rows; widths in {16, 32, 64, 128}; 3xbf16
  * contraction as K4 (exact = 0).  The re-bracketing changes fp32 rounding order only.
  * ------------------------------------------------------------------------------------------- */
 int gwen_gcn_chain_supported(int64_t Fin, int64_t F1, int64_t F2, int pre);
@@ -145,8 +148,8 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
  *   layer's projection (K5) when that layer is AUTO too and shrinks, so that it is gathered at its
  *   narrow width -- otherwise transform-first (K3 then K2) when fout <= fin, aggregate-first (K2
  *   then K3) when fin < fout.  Explicit orders are taken literally, layer by layer.
- * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4 layers;
- *   may be NULL when no layer resolves to K4).
+ * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4/K5 layers;
+ *   g_col/g_val may be NULL when no layer resolves to K4/K5, g_rowptr NULL = uniform layout).
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
  * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
  * events (HOST array of hipEvent_t, or NULL): if given, events[2i] / events[2i+1] are recorded on

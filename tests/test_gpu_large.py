@@ -1,0 +1,77 @@
+"""Larger and skewed inputs on the device: beyond-L2 meshes, long rows, many members."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import REL_TOL, SEED, make_params, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ga(hip_lib):
+    import gwen_amd
+    return gwen_amd
+
+
+def test_nine_hundred_thousand_node_mesh_layer(ga):
+    """nu = 300: N = 900 002, E = 5 400 000 (x = 230 MB at F = 64, beyond L2 and close to the Infinity
+    Cache): one fused layer against the CPU oracle, linearity and determinism."""
+    from oracle import gcn_oracle as O
+    m = ga.geodesic_mesh(300)
+    n = m.num_nodes
+    assert (n, m.num_edges) == (900002, 5400000)
+    ei = torch.from_numpy(m.edge_index)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(64, 64)
+    conv = ga.GCNConv(64, 64).to(DEV)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+        eid = ei.to(DEV)
+        got = conv(x.to(DEV), eid, relu=True)
+        assert torch.equal(got, conv(x.to(DEV), eid, relu=True))
+        ref = torch.relu(O.gcn_conv(x, ei, w, b))
+    assert rel_err(got, ref) <= REL_TOL
+
+
+def test_long_rows_complete_graph_1000(ga):
+    """K_1000: 999 000 edges, every row 1000 entries (125 groups of 8) -- the long-row loops of K2/K4/K5."""
+    n = 1000
+    ei = torch.from_numpy(ga.complete_graph(n)).to(DEV)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(64, 32)
+    want = (x.double() @ w.double().t()).mean(0, keepdim=True) + b.double()       # K_N identity
+    for order in ("auto", "fused_exact", "transform_first", "aggregate_first"):
+        conv = ga.GCNConv(64, 32).to(DEV)
+        conv.order = order
+        with torch.no_grad():
+            conv.lin.weight.copy_(w); conv.bias.copy_(b)
+            got = conv(x.to(DEV), ei).cpu().double()
+        assert rel_err(got, want.expand_as(got)) <= 2e-5, order
+
+
+def test_star_graph_one_heavy_row(ga, cref):
+    """One destination with 50 000 in-edges next to 50 000 single-entry rows (load skew)."""
+    n = 50001
+    ei = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)])
+    x = torch.randn(n, 32, generator=torch.Generator().manual_seed(SEED))
+    w, b = make_params(32, 32)
+    ref = torch.from_numpy(cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True))
+    conv = ga.GCNConv(32, 32).to(DEV)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+        got = conv(x.to(DEV), ei.to(DEV), relu=True).cpu()
+    assert rel_err(got, ref) <= REL_TOL
+
+
+def test_sixteen_members_share_one_graph(ga):
+    m = ga.geodesic_mesh(20)
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(1, 1, 64, 64, 64)).to(DEV).eval()
+    x = torch.randn(16, m.num_nodes, 64, device=DEV)
+    with torch.no_grad():
+        batched = model(x, ei)
+        one = model(x[5], ei)
+    assert torch.equal(batched[5], one)

@@ -98,7 +98,15 @@ def test_grouped_layout(ga, case):
     name, n, ei = case
     g = ga.prepare_graph(ei.to(DEV), n)
     rp, col, val = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy()
-    grp, gcol, gval = (t.cpu().numpy() for t in g.grouped())
+    grp_t, gcol_t, gval_t = g.grouped()
+    gcol, gval = gcol_t.cpu().numpy(), gval_t.cpu().numpy()
+    lens = np.diff(rp)
+    if grp_t is None:                                   # uniform layout: every row exactly one group
+        assert n > 0 and ((lens >= 1) & (lens <= 8)).all()
+        grp = 8 * np.arange(n + 1)
+    else:
+        assert n == 0 or not ((lens >= 1) & (lens <= 8)).all()
+        grp = grp_t.cpu().numpy()
     assert grp[0] == 0 and (np.diff(grp) % 8 == 0).all()
     for r in range(n):
         ln = rp[r + 1] - rp[r]
@@ -311,7 +319,7 @@ def test_grouped_gather_kernel(ga, cref, case, F):
     want = ops.propagate(g, h, b, True)
     out = torch.empty_like(h)
     gr, gc, gv = g.grouped()
-    rc = _lib.lib().gwen_gcn_chain_f32(_ptr(gr), _ptr(gc), _ptr(gv), _ptr(h), None, None, _ptr(b), _ptr(out),
+    rc = _lib.lib().gwen_gcn_chain_f32(None if gr is None else _ptr(gr), _ptr(gc), _ptr(gv), _ptr(h), None, None, _ptr(b), _ptr(out),
                                        n, F, 0, 0, 1, 1, 1, n * F, n * F, _stream(h.device))
     assert rc == 0
     assert rel_err(out, want) <= 2e-6
