@@ -17,13 +17,11 @@
 // :204-206; the re-bracketing only changes fp32 rounding order).
 // Structure, layout, contraction (3xbf16 split, fp32 accumulate) and numerics are K4's (layer.hip).
 #include "common.h"
+#include "gather_rows.h"
 
 namespace {
 
 constexpr int kTile = 16;
-constexpr int kBatch = 8;
-typedef int int4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -123,9 +121,7 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
 
   const char *xb = reinterpret_cast<const char *>(x + (int64_t)blockIdx.y * mstride_x);
   float *om = out + (int64_t)blockIdx.y * mstride_o;
-  constexpr uint32_t kRowBytes = FIN * 4;
   const uint32_t lane_off = gl * 16;
-  const int32_t null_off = UNI ? 8 * N : rowptr[N];
 
   // weights of both contractions for this wave's column tiles, issued before the gathers
   const int j1 = wave % C::NJ1;
@@ -140,54 +136,21 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
   else               { if (bias) bpost = bias[j1 * 16 + mi]; }
 
   // ---- phase 1: gather + aggregate (+ bias, ReLU when activation-first) -> LDS hi/lo -------------
+  gwen::gather_passes<FIN, C::NP, C::RB, UNI>(
+      rowptr, col, val, xb, N, b0, wave, gr, lane_off, [&](int lr, float4_t acc) {
+        if constexpr (PRE) {
+          acc = acc + bpre;
+          if (relu) {
 #pragma unroll
-  for (int p = 0; p < C::NP; ++p) {
-    const int lr = p * C::RB + wave * C::R + gr;
-    const int r = b0 + lr;
-    const bool ok = r < N;
-    int32_t s, rb;
-    if constexpr (UNI) {          // every row is exactly one group: no rowptr lookup, no loop
-      s = ok ? 8 * r : 8 * N;
-      rb = 0;
-    } else {
-      const int32_t ra = rowptr[ok ? r : N];
-      rb = rowptr[ok ? r + 1 : N];
-      s = rb > ra ? ra : null_off;
-    }
-    float4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (;;) {
-      const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
-      const int4_u c1 = *reinterpret_cast<const int4_u *>(col + s + 4);
-      const float4_u w0 = *reinterpret_cast<const float4_u *>(val + s);
-      const float4_u w1 = *reinterpret_cast<const float4_u *>(val + s + 4);
-      float4_t v[kBatch];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c0[u] * kRowBytes + lane_off));
-        v[u + 4] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c1[u] * kRowBytes + lane_off));
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc = __builtin_elementwise_fma(float4_t{w0[u], w0[u], w0[u], w0[u]}, v[u], acc);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc = __builtin_elementwise_fma(float4_t{w1[u], w1[u], w1[u], w1[u]}, v[u + 4], acc);
-      s += kBatch;
-      if (s >= rb) break;
-    }
-    if constexpr (PRE) {
-      acc = acc + bpre;
-      if (relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = acc[e] < 0.0f ? 0.0f : acc[e];
-      }
-    }
-    const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
-    bf16x4 h4, l4;
-    split_bf16<4>(a4, h4, l4);
-    *reinterpret_cast<bf16x4 *>(t0hi + lr * C::PB0 + gl * 4) = h4;
-    *reinterpret_cast<bf16x4 *>(t0lo + lr * C::PB0 + gl * 4) = l4;
-  }
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] < 0.0f ? 0.0f : acc[e];
+          }
+        }
+        const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
+        bf16x4 h4, l4;
+        split_bf16<4>(a4, h4, l4);
+        *reinterpret_cast<bf16x4 *>(t0hi + lr * C::PB0 + gl * 4) = h4;
+        *reinterpret_cast<bf16x4 *>(t0lo + lr * C::PB0 + gl * 4) = l4;
+      });
   __syncthreads();
 
   // ---- phase 2: first contraction; result to global (F2 == 0) or to the second LDS image ----------
@@ -241,48 +204,19 @@ __global__ __launch_bounds__(256) void k_gather(
   const int nb = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nb >> 3, r8 = nb & 7;
   const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int r = lb * BR + wave * R + gr;
   const char *xb = reinterpret_cast<const char *>(x + (int64_t)blockIdx.y * mstride_x);
   float *om = out + (int64_t)blockIdx.y * mstride_o;
-  constexpr uint32_t kRowBytes = FIN * 4;
   const uint32_t lane_off = gl * 16;
-  const bool ok = r < N;
-  int32_t s, rb;
-  if constexpr (UNI) {
-    s = ok ? 8 * r : 8 * N;
-    rb = 0;
-  } else {
-    const int32_t ra = rowptr[ok ? r : N];
-    rb = rowptr[ok ? r + 1 : N];
-    s = rb > ra ? ra : rowptr[N];
-  }
-  float4_t acc = {0.f, 0.f, 0.f, 0.f};
-  for (;;) {
-    const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
-    const int4_u c1 = *reinterpret_cast<const int4_u *>(col + s + 4);
-    const float4_u w0 = *reinterpret_cast<const float4_u *>(val + s);
-    const float4_u w1 = *reinterpret_cast<const float4_u *>(val + s + 4);
-    float4_t v[kBatch];
+  gwen::gather_passes<FIN, 1, BR, UNI>(
+      rowptr, col, val, xb, N, lb * BR, wave, gr, lane_off, [&](int lr, float4_t acc) {
+        if (bias) acc = acc + *reinterpret_cast<const float4_t *>(bias + gl * 4);
+        if (relu) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      v[u] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c0[u] * kRowBytes + lane_off));
-      v[u + 4] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c1[u] * kRowBytes + lane_off));
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      acc = __builtin_elementwise_fma(float4_t{w0[u], w0[u], w0[u], w0[u]}, v[u], acc);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      acc = __builtin_elementwise_fma(float4_t{w1[u], w1[u], w1[u], w1[u]}, v[u + 4], acc);
-    s += kBatch;
-    if (s >= rb) break;
-  }
-  if (bias) acc = acc + *reinterpret_cast<const float4_t *>(bias + gl * 4);
-  if (relu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = acc[e] < 0.0f ? 0.0f : acc[e];
-  }
-  if (ok) *reinterpret_cast<float4_t *>(om + (int64_t)r * FIN + gl * 4) = acc;
+          for (int e = 0; e < 4; ++e) acc[e] = acc[e] < 0.0f ? 0.0f : acc[e];
+        }
+        if (lb * BR + lr < N)
+          *reinterpret_cast<float4_t *>(om + (int64_t)(lb * BR + lr) * FIN + gl * 4) = acc;
+      });
 }
 
 template <int FIN>

@@ -28,13 +28,11 @@
 //   row pitch Fin+4 floats => conflict-free 8-B reads): bit-exact fp32 fmaf chains.
 // Blocks are remapped so that the blocks sharing an XCD (blockIdx % 8) own neighbouring rows.
 #include "common.h"
+#include "gather_rows.h"
 
 namespace {
 
 constexpr int kTile = 16;
-constexpr int kBatch = 8;
-typedef int int4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -94,9 +92,7 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
 
   const char *xb = reinterpret_cast<const char *>(x + (int64_t)blockIdx.y * mstride_x);
   float *om = out + (int64_t)blockIdx.y * mstride_o;
-  constexpr uint32_t kRowBytes = FIN * 4;                  // x rows are contiguous (ldx == Fin)
-  const uint32_t lane_off = gl * 16;
-  const int32_t null_off = UNI ? 8 * N : rowptr[N];
+  const uint32_t lane_off = gl * 16;                       // x rows are contiguous (ldx == Fin)
 
   // ---- this wave's B fragments (its 16 output columns of W^T), issued before the gathers ---------
   const int j = wave % C::NJ;
@@ -123,52 +119,19 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   }
   const float bv = bias ? bias[j * 16 + mi] : 0.0f;
 
-  // ---- phase 1: gather + aggregate into the LDS tile ---------------------------------------------
-#pragma unroll
-  for (int p = 0; p < C::NP; ++p) {
-    const int lr = p * C::RB + wave * C::R + gr;
-    const int r = b0 + lr;
-    const bool ok = r < N;
-    int32_t s, rb;
-    if constexpr (UNI) {          // every row is exactly one group: no rowptr lookup, no loop
-      s = ok ? 8 * r : 8 * N;
-      rb = 0;
-    } else {
-      const int32_t ra = rowptr[ok ? r : N];
-      rb = rowptr[ok ? r + 1 : N];
-      s = rb > ra ? ra : null_off;
-    }
-    float4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (;;) {
-      const int4_u c0 = *reinterpret_cast<const int4_u *>(col + s);
-      const int4_u c1 = *reinterpret_cast<const int4_u *>(col + s + 4);
-      const float4_u w0 = *reinterpret_cast<const float4_u *>(val + s);
-      const float4_u w1 = *reinterpret_cast<const float4_u *>(val + s + 4);
-      float4_t v[kBatch];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c0[u] * kRowBytes + lane_off));
-        v[u + 4] = *reinterpret_cast<const float4_t *>(xb + (uint64_t)((uint32_t)c1[u] * kRowBytes + lane_off));
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc = __builtin_elementwise_fma(float4_t{w0[u], w0[u], w0[u], w0[u]}, v[u], acc);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc = __builtin_elementwise_fma(float4_t{w1[u], w1[u], w1[u], w1[u]}, v[u + 4], acc);
-      s += kBatch;
-      if (s >= rb) break;                 // rows longer than one group of 8 (rb <= ra ends at once)
-    }
-    if constexpr (SPLIT) {
-      const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
-      bf16x4 h4, l4;
-      split_bf16<4>(a4, h4, l4);
-      *reinterpret_cast<bf16x4 *>(thi + lr * C::PB + gl * 4) = h4;
-      *reinterpret_cast<bf16x4 *>(tlo + lr * C::PB + gl * 4) = l4;
-    } else {
-      *reinterpret_cast<float4_t *>(tile + lr * C::PF + gl * 4) = acc;
-    }
-  }
+  // ---- phase 1: gather + aggregate into the LDS tile (gather_rows.h) ------------------------------
+  gwen::gather_passes<FIN, C::NP, C::RB, UNI>(
+      rowptr, col, val, xb, N, b0, wave, gr, lane_off, [&](int lr, float4_t acc) {
+        if constexpr (SPLIT) {
+          const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
+          bf16x4 h4, l4;
+          split_bf16<4>(a4, h4, l4);
+          *reinterpret_cast<bf16x4 *>(thi + lr * C::PB + gl * 4) = h4;
+          *reinterpret_cast<bf16x4 *>(tlo + lr * C::PB + gl * 4) = l4;
+        } else {
+          *reinterpret_cast<float4_t *>(tile + lr * C::PF + gl * 4) = acc;
+        }
+      });
   __syncthreads();
 
   // ---- phase 2: (tile) x (this wave's 16 columns of W^T), bias, ReLU, store ----------------------
