@@ -63,20 +63,21 @@ struct Frag {
       split_bf16<KF>(wv, hi[ks], lo[ks]);
     }
   }
-  // d += A(tile rows arow.., from the hi/lo LDS images) x B
+  // d += W-fragment (A operand) x tile rows arow.. from the hi/lo LDS images (B operand): the product
+  // comes out TRANSPOSED -- lane (mi, mh) holds row mi, columns 16 j + 4 mh .. +3
   __device__ inline f32x4 mma(const __bf16 *thi, const __bf16 *tlo, int arow, int mh, f32x4 d) const {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const T ahi = *reinterpret_cast<const T *>(thi + arow + KF * (4 * ks + mh));
       const T alo = *reinterpret_cast<const T *>(tlo + arow + KF * (4 * ks + mh));
       if constexpr (KF == 8) {
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, hi[ks], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, lo[ks], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, hi[ks], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[ks], alo, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo[ks], ahi, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi[ks], ahi, d, 0, 0, 0);
       } else {
-        d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(alo, hi[ks], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ahi, lo[ks], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ahi, hi[ks], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi[ks], alo, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(lo[ks], ahi, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi[ks], ahi, d, 0, 0, 0);
       }
     }
     return d;
@@ -130,10 +131,9 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
   const int j2 = wave % (F2 > 0 ? C::NJ2 : 1);
   Frag<(F2 > 0 ? F1 : 16)> b2;
   if constexpr (F2 > 0) b2.load(W2, j2, mi, mh);
-  float4_t bpre = {0.f, 0.f, 0.f, 0.f};
-  float bpost = 0.0f;
+  float4_t bpre = {0.f, 0.f, 0.f, 0.f}, bpost = {0.f, 0.f, 0.f, 0.f};
   if constexpr (PRE) { if (bias) bpre = *reinterpret_cast<const float4_t *>(bias + gl * 4); }
-  else               { if (bias) bpost = bias[j1 * 16 + mi]; }
+  else               { if (bias) bpost = *reinterpret_cast<const float4_t *>(bias + j1 * 16 + 4 * mh); }
 
   // ---- phase 1: gather + aggregate (+ bias, ReLU when activation-first) -> LDS hi/lo -------------
   gwen::gather_passes<FIN, C::NP, C::RB, UNI>(
@@ -158,21 +158,24 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
   for (int tt = wave / C::NJ1; tt < C::NT; tt += C::NWB / C::NJ1) {
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
     d = b1.mma(t0hi, t0lo, (tt * kTile + mi) * C::PB0, mh, d);
+    const int lr = tt * kTile + mi;
+    float4_t o = {d[0], d[1], d[2], d[3]};
+    if constexpr (!PRE) {
+      o = o + bpost;
+      if (relu) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int lr = tt * kTile + 4 * mh + t;
-      float vv = d[t];
-      if constexpr (!PRE) {
-        vv = vv + bpost;
-        if (relu) vv = vv < 0.0f ? 0.0f : vv;
+        for (int t = 0; t < 4; ++t) o[t] = o[t] < 0.0f ? 0.0f : o[t];
       }
-      if constexpr (F2 > 0) {
-        const __bf16 h = (__bf16)vv;
-        t1hi[lr * C::PB1 + j1 * 16 + mi] = h;
-        t1lo[lr * C::PB1 + j1 * 16 + mi] = (__bf16)(vv - (float)h);
-      } else {
-        if (b0 + lr < N) om[(int64_t)(b0 + lr) * F1 + j1 * 16 + mi] = vv;
-      }
+    }
+    if constexpr (F2 > 0) {
+      const float o4[4] = {o[0], o[1], o[2], o[3]};
+      bf16x4 h4, l4;
+      split_bf16<4>(o4, h4, l4);
+      *reinterpret_cast<bf16x4 *>(t1hi + lr * C::PB1 + j1 * 16 + 4 * mh) = h4;
+      *reinterpret_cast<bf16x4 *>(t1lo + lr * C::PB1 + j1 * 16 + 4 * mh) = l4;
+    } else {
+      if (b0 + lr < N)
+        *reinterpret_cast<float4_t *>(om + (int64_t)(b0 + lr) * F1 + j1 * 16 + 4 * mh) = o;
     }
   }
   if constexpr (F2 > 0) {
@@ -182,11 +185,10 @@ __global__ __launch_bounds__((F1 > 64 ? 512 : 256)) void k_chain(
     for (int tt = wave / C::NJ2; tt < C::NT; tt += C::NWB / C::NJ2) {
       f32x4 d = {0.f, 0.f, 0.f, 0.f};
       d = b2.mma(t1hi, t1lo, (tt * kTile + mi) * C::PB1, mh, d);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = b0 + tt * kTile + 4 * mh + t;
-        if (r < N) om[(int64_t)r * F2 + j2 * 16 + mi] = d[t];
-      }
+      const int r = b0 + tt * kTile + mi;
+      if (r < N)
+        *reinterpret_cast<float4_t *>(om + (int64_t)r * F2 + j2 * 16 + 4 * mh) =
+            float4_t{d[0], d[1], d[2], d[3]};
     }
   }
 }

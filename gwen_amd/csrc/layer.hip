@@ -17,7 +17,8 @@
 //            output columns -- straight from global memory (16 KB, L1/L2-resident) into registers;
 //   barrier;
 //   phase 2  wave w owns output-column tile j = w % NJ of every (NWB/NJ)-th 16-row tile: A fragments
-//            from LDS, MFMAs, + bias, ReLU, direct stores from the D layout.
+//            from LDS, MFMAs with W as the A operand (so the D tile comes out transposed: one lane =
+//            4 consecutive output columns of one row), + bias, ReLU, one 16-B store per lane.
 // Contraction (default): "3xbf16" -- x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and
 //   x.w ~= lo.hi' + hi.lo' + hi.hi' on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the dropped
 //   lo.lo' term and the representation residual are < 2^-16 relative each (measured 8e-6 relative on
@@ -117,7 +118,8 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
     for (int q = 0; q < C::NQ; ++q)
       bfr[q] = *reinterpret_cast<const float2_t *>(wrow + 8 * q + 2 * mh);
   }
-  const float bv = bias ? bias[j * 16 + mi] : 0.0f;
+  float4_t bv4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv4 = *reinterpret_cast<const float4_t *>(bias + j * 16 + 4 * mh);
 
   // ---- phase 1: gather + aggregate into the LDS tile (gather_rows.h) ------------------------------
   gwen::gather_passes<FIN, C::NP, C::RB, UNI>(
@@ -146,13 +148,13 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
         const FT ahi = *reinterpret_cast<const FT *>(thi + arow + C::KF * (4 * ks + mh));
         const FT alo = *reinterpret_cast<const FT *>(tlo + arow + C::KF * (4 * ks + mh));
         if constexpr (C::KF == 8) {
-          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[ks], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[ks], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[ks], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ks], alo, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ks], ahi, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ks], ahi, d, 0, 0, 0);
         } else {
-          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(alo, bhi[ks], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ahi, blo[ks], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ahi, bhi[ks], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bhi[ks], alo, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(blo[ks], ahi, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bhi[ks], ahi, d, 0, 0, 0);
         }
       }
     } else {
@@ -160,18 +162,19 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
 #pragma unroll
       for (int q = 0; q < C::NQ; ++q) {
         const float2_t a = *reinterpret_cast<const float2_t *>(ap + 8 * q);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bfr[q][0], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bfr[q][1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[q][0], a[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[q][1], a[1], d, 0, 0, 0);
       }
     }
-    // D[row = 4*mh + t][col = 16 j + mi]: one instruction stores 4 rows x 64 B
+    // W is the A operand, so D is the TRANSPOSED tile: lane (mi, mh) holds destination row mi,
+    // output columns 16 j + 4 mh .. +3 -- one 16-B store per lane, 16 rows x 64 B per instruction
+    const int r = b0 + tt * kTile + mi;
+    float4_t o = float4_t{d[0], d[1], d[2], d[3]} + bv4;
+    if (relu) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = b0 + tt * kTile + 4 * mh + t;
-      float vv = d[t] + bv;
-      if (relu) vv = vv < 0.0f ? 0.0f : vv;
-      if (r < N) om[(int64_t)r * ldo + j * 16 + mi] = vv;
+      for (int t = 0; t < 4; ++t) o[t] = o[t] < 0.0f ? 0.0f : o[t];
     }
+    if (r < N) *reinterpret_cast<float4_t *>(om + (int64_t)r * ldo + j * 16 + 4 * mh) = o;
   }
 }
 
@@ -213,7 +216,7 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
   if (!col || !val || !x || !W || !out || x == out) return GWEN_EINVAL;   // rowptr NULL = uniform
   if (N >= (int64_t(1) << 28) || members > 65535) return GWEN_ERANGE;     // 8 N must fit int32
   if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || !gwen_aligned(W, 16) || ldx != Fin ||
-      mstride_x % 4)
+      mstride_x % 4 || ldo % 4 || mstride_o % 4 || (bias && !gwen_aligned(bias, 16)))
     return GWEN_EINVAL;                       // x rows must be contiguous (32-bit row offsets)
   if (N * Fin * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
