@@ -10,8 +10,8 @@
 namespace {
 
 struct Plan {
-  int64_t ping, pong, tmp;   // element offsets into scratch
-  int64_t total;
+  int64_t ping, pong, tmp, lin;   // element offsets into scratch (lin: split-K workspace of K3)
+  int64_t lin_floats, total;
 };
 
 inline int resolve_order(const gwen_layer_desc &L) {
@@ -39,10 +39,17 @@ int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t
     if (o == GWEN_ORDER_AGGREGATE_FIRST && L.fin > tmp_w) tmp_w = L.fin;
   }
   const int64_t rows = members * N;
+  int64_t lin_w = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const int64_t w = gwen_gcn_linear_workspace_floats(rows, layers[i].fin, layers[i].fout);
+    if (w > lin_w) lin_w = w;
+  }
   P->ping = 0;
   P->pong = round4(rows * out_w);
   P->tmp = P->pong + round4(rows * out_w);
-  P->total = P->tmp + round4(rows * tmp_w) + 4;
+  P->lin = P->tmp + round4(rows * tmp_w);
+  P->lin_floats = lin_w;
+  P->total = P->lin + round4(lin_w) + 4;
   return GWEN_OK;
 }
 
@@ -75,6 +82,7 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
   const int64_t rows = members * N;
   float *buf[2] = {scratch + P.ping, scratch + P.pong};
   float *tmp = scratch + P.tmp;
+  float *lin_ws = scratch + P.lin;
   int32_t nl = 0;
 
   auto before = [&](int kind, int layer, int fin, int fout) -> int {
@@ -155,7 +163,8 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
       float *dst = last ? out : buf[nbuf++ & 1];
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
-      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, L.order != GWEN_ORDER_AUTO, stream));
+      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, L.order != GWEN_ORDER_AUTO, lin_ws,
+                                   P.lin_floats, stream));
       GWEN_TRY(after());
       GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fo, fo));
       GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, tmp, L.bias, dst, N, fo, fo, fo, members,
@@ -169,7 +178,8 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
                                       N * fi, N * fi, 0, stream));
       GWEN_TRY(after());
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
-      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, L.order != GWEN_ORDER_AUTO, stream));
+      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, L.order != GWEN_ORDER_AUTO,
+                                   lin_ws, P.lin_floats, stream));
       GWEN_TRY(after());
       cur = dst;
     } else {

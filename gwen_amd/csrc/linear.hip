@@ -157,7 +157,9 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ h, int64_t rows,
                                                            int Fin, int Fout, int64_t ldx,
-                                                           int64_t ldh, int relu) {
+                                                           int64_t ldh, int relu, int kchunk) {
+  // split-K: blockIdx.z contracts k in [z * kchunk, min(Fin, (z+1) * kchunk)) and writes its RAW partial
+  // product to slab z of h (h is then the workspace, ldh = Fout; bias/ReLU happen in the reduction)
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * 128 * SPB];
   __bf16 *ahi = lds, *alo = lds + 128 * SPB, *bhi = lds + 2 * 128 * SPB, *blo = lds + 3 * 128 * SPB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -171,18 +173,22 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int k_lo = blockIdx.z * kchunk;
+  const int k_hi = k_lo + kchunk < Fin ? k_lo + kchunk : Fin;
+  const bool partial = gridDim.z > 1;
+  if (partial) h += (int64_t)blockIdx.z * rows * Fout;
   float4_t pa[4], pb[4];
-  slab_load<VEC>(x, ldx, row0, rows, 0, Fin, pa);
-  slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout), 0, Fin, pb);
+  slab_load<VEC>(x, ldx, row0, rows, k_lo, k_hi, pa);
+  slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout), k_lo, k_hi, pb);
   slab_store(pa, ahi, alo);
   slab_store(pb, bhi, blo);
   __syncthreads();
-  for (int k0 = 0; k0 < Fin; k0 += SBK) {
-    const bool more = k0 + SBK < Fin;
+  for (int k0 = k_lo; k0 < k_hi; k0 += SBK) {
+    const bool more = k0 + SBK < k_hi;
     // issued unconditionally (past the last slab the loads are clamped and their result unused)
-    slab_load<VEC>(x, ldx, row0, rows, k0 + SBK, Fin, pa);
+    slab_load<VEC>(x, ldx, row0, rows, k0 + SBK, k_hi, pa);
     slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout),
-                   k0 + SBK, Fin, pb);
+                   k0 + SBK, k_hi, pb);
     bf16x8 fah[2], fal[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
   for (int ct = 0; ct < NCT; ++ct) {
     const int c = col0 + ct * 16 + mi;
     if (c >= Fout) continue;
-    const float bv = bias ? bias[c] : 0.0f;
+    const float bv = (bias && !partial) ? bias[c] : 0.0f;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -223,17 +229,51 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
         const int64_t r = row0 + wave * 32 + rt * 16 + 4 * mh + t;
         if (r >= rows) continue;
         float v = acc[rt][ct][t] + bv;
-        if (relu) v = v < 0.0f ? 0.0f : v;
+        if (relu && !partial) v = v < 0.0f ? 0.0f : v;
         h[r * ldh + c] = v;
       }
   }
 }
 
+// out[r][c] = act(sum_z partial[z][r][c] + bias[c]), slabs added in ascending z (deterministic)
+__global__ void k_splitk_reduce(const float *__restrict__ partial, const float *__restrict__ bias,
+                                float *__restrict__ out, int64_t rows, int Fout, int64_t ldh,
+                                int nsplit, int relu) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= rows * Fout) return;
+  const int64_t r = i / Fout;
+  const int c = (int)(i - r * Fout);
+  float s = 0.0f;
+  for (int z = 0; z < nsplit; ++z) s = s + partial[(int64_t)z * rows * Fout + i];
+  if (bias) s = s + bias[c];
+  if (relu) s = s < 0.0f ? 0.0f : s;
+  out[r * ldh + c] = s;
+}
+
+// split-K pays when the output tiles alone cannot fill the chip and K is long: few rows x wide input
+// (the reference's own C -> 1024 projection on ~125 member-nodes)
+inline int splitk_factor(int64_t rows, int64_t Fin, int64_t Fout) {
+  const int64_t bn = Fout <= 64 ? 64 : SBN;
+  const int64_t blocks = ((rows + SBM - 1) / SBM) * ((Fout + bn - 1) / bn);
+  if (blocks >= 256 || Fin < 1024) return 1;
+  int64_t n = (512 + blocks - 1) / blocks;           // aim at ~512 blocks
+  const int64_t maxn = Fin / 256;                      // at least 256 of K per block
+  if (n > maxn) n = maxn;
+  return n < 2 ? 1 : (int)n;
+}
+
 }  // namespace
+
+extern "C" int64_t gwen_gcn_linear_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout) {
+  if (rows <= 0 || Fin <= 0 || Fout <= 0) return 0;
+  const int n = splitk_factor(rows, Fin, Fout);
+  return n > 1 ? (int64_t)n * rows * Fout : 0;
+}
 
 extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float *h,
                                    int64_t rows, int64_t Fin, int64_t Fout, int64_t ldx,
-                                   int64_t ldh, int relu, int exact, gwen_stream_t stream_) {
+                                   int64_t ldh, int relu, int exact, float *workspace,
+                                   int64_t workspace_floats, gwen_stream_t stream_) {
   if (rows < 0 || Fin < 0 || Fout < 0 || ldx < Fin || ldh < Fout) return GWEN_EINVAL;
   if (rows == 0 || Fout == 0) return GWEN_OK;
   if (!h || (Fin > 0 && (!x || !W))) return GWEN_EINVAL;
@@ -244,14 +284,26 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
     const int bn = Fout <= 64 ? 64 : SBN;           // narrow outputs: 64-column blocks, no empty tiles
     const int64_t sx = (rows + SBM - 1) / SBM, sy = (Fout + bn - 1) / bn;
     if (sx > 0x7fffffffLL || sy > 65535) return GWEN_ERANGE;
-    dim3 sgrid((unsigned)sx, (unsigned)sy);
+    int nsplit = splitk_factor(rows, Fin, Fout);
+    if (nsplit > 1 && (!workspace || workspace_floats < (int64_t)nsplit * rows * Fout)) nsplit = 1;
+    const int kchunk = nsplit > 1 ? (int)(((Fin + nsplit - 1) / nsplit + SBK - 1) / SBK * SBK) : (int)Fin;
+    const int nz = (int)((Fin + kchunk - 1) / kchunk);
+    dim3 sgrid((unsigned)sx, (unsigned)sy, (unsigned)nz);
+    float *dst = nz > 1 ? workspace : h;
+    const int64_t dld = nz > 1 ? Fout : ldh;
 #define GWEN_LS(V, T)                                                                             \
-  k_linear_split<V, T><<<sgrid, kThreads, 0, st>>>(x, W, bias, h, rows, (int)Fin, (int)Fout, ldx,  \
-                                                   ldh, relu)
+  k_linear_split<V, T><<<sgrid, kThreads, 0, st>>>(x, W, bias, dst, rows, (int)Fin, (int)Fout, ldx, \
+                                                   dld, relu, kchunk)
     if (vec) { if (bn == 64) GWEN_LS(true, 4); else GWEN_LS(true, 8); }
     else     { if (bn == 64) GWEN_LS(false, 4); else GWEN_LS(false, 8); }
 #undef GWEN_LS
     GWEN_LAUNCH_CHECK();
+    if (nz > 1) {
+      const int64_t count = rows * Fout;
+      k_splitk_reduce<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(workspace, bias, h, rows,
+                                                                       (int)Fout, ldh, nz, relu);
+      GWEN_LAUNCH_CHECK();
+    }
     return GWEN_OK;
   }
   const int64_t gx = (rows + BM - 1) / BM, gy = (Fout + BN - 1) / BN;

@@ -10,7 +10,7 @@
 // holding V consecutive floats (V = 4 -> 16-B loads); 256/G items per 256-thread block.
 //   F = 64 -> G = 16, four destination rows per wave; F = 256 -> one wave per row;
 //   F = 16 -> G = 4.  Wider F loops over chunks of G*V features (item = row * nchunks + chunk).
-// The neighbour list is walked U = 4 at a time: indices/weights first, then U independent row
+// The neighbour list is walked U = 8 at a time: indices/weights first, then U independent row
 // gathers in flight, then the adds in stored order, each product rounded before its add (no FMA;
 // this TU is compiled with -ffp-contract=off), so out is bit-identical to a sequential CPU
 // scatter-add in edge order and identical run to run.
@@ -48,7 +48,7 @@ __device__ inline typename Vec<V>::T vrelu(typename Vec<V>::T v) {
 }
 
 constexpr int kBlock = 256;
-constexpr int kUnroll = 4;
+constexpr int kUnroll = 8;
 
 template <int G, int V, bool REMAP>
 __global__ __launch_bounds__(kBlock) void k_propagate(

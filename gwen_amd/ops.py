@@ -75,9 +75,14 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool 
         _require(bias, "bias")
         bias = bias.contiguous()
     dev = x.device
+    ws = None
+    nws = 0 if exact else int(_lib.lib().gwen_gcn_linear_workspace_floats(rows, fin, fout))
+    if nws > 0:
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)          # split-K partial products
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_linear_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), rows, fin,
-                                            fout, fin, fout, int(relu), int(exact), _stream(dev))
+                                            fout, fin, fout, int(relu), int(exact), _ptr(ws), nws,
+                                            _stream(dev))
     _lib.check(rc, "gwen_gcn_linear_f32")
     return out
 

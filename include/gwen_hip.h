@@ -100,10 +100,15 @@ int gwen_gcn_propagate_f32(const int32_t *rowptr, const int32_t *col, const floa
  * (row stride ldh).  Optional epilogue: + bias[Fout] (NULL = none), ReLU.
  * exact = 0: 3xbf16 split contraction, fp32 accumulate (as K4; < 2^-15 relative per product);
  * exact = 1: fp32-input MFMA (v_mfma_f32_32x32x2_f32), bit-identical to a k-ordered fp32 fmaf chain.
+ * workspace (optional, gwen_gcn_linear_workspace_floats() elements; 0 = not needed): lets the split
+ *   variant cut a long K over several blocks when there are few output tiles (few rows x wide input,
+ *   the reference's own C -> 1024 projection on ~125 nodes) and add the partial products in a fixed
+ *   order; without it that shape runs on a handful of CUs.
  * ------------------------------------------------------------------------------------------- */
+int64_t gwen_gcn_linear_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout);
 int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows,
                         int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldh, int relu, int exact,
-                        gwen_stream_t stream);
+                        float *workspace, int64_t workspace_floats, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  one whole GCNConv layer (+ReLU) in a single launch, aggregate-first:

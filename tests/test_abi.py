@@ -43,8 +43,10 @@ def test_argument_validation_without_gpu(hip_lib):
     assert hip_lib.gwen_gcn_propagate_f32(None, None, None, None, None, None, -1, 4, 4, 4, 1, 0, 0, 0, None) == -1
     assert hip_lib.gwen_gcn_propagate_f32(None, None, None, None, None, None, 0, 4, 4, 4, 1, 0, 0, 0, None) == 0
     assert hip_lib.gwen_gcn_propagate_f32(None, None, None, None, None, None, 5, 4, 2, 4, 1, 0, 0, 0, None) == -1
-    assert hip_lib.gwen_gcn_linear_f32(None, None, None, None, 5, 4, 4, 2, 4, 0, 0, None) == -1
-    assert hip_lib.gwen_gcn_linear_f32(None, None, None, None, 0, 4, 4, 4, 4, 0, 0, None) == 0
+    assert hip_lib.gwen_gcn_linear_f32(None, None, None, None, 5, 4, 4, 2, 4, 0, 0, None, 0, None) == -1
+    assert hip_lib.gwen_gcn_linear_f32(None, None, None, None, 0, 4, 4, 4, 4, 0, 0, None, 0, None) == 0
+    assert hip_lib.gwen_gcn_linear_workspace_floats(100000, 64, 64) == 0
+    assert hip_lib.gwen_gcn_linear_workspace_floats(125, 16384, 1024) == 64 * 125 * 1024
     assert hip_lib.gwen_gcn_prep(None, None, -1, 0, 1, 1.0, 1, None, None, None, None, None, None, None, 0, None) == -1
     assert hip_lib.gwen_gcn_prep(8, None, 2 ** 31, 5, 1, 1.0, 1, 1, None, None, None, None, 1, None, 0, None) == -2
     assert hip_lib.gwen_relu_backward_f32(None, None, None, 0, None) == 0

@@ -158,7 +158,7 @@ def test_propagate_members_and_determinism(ga, cref):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,fin,fout", [(1002, 8, 8), (1002, 64, 64), (777, 64, 32), (130, 16, 32),
                                             (1002, 256, 256), (125, 1000, 48), (33, 7, 5), (64, 3, 1),
-                                            (10, 0, 4), (129, 100, 260)])
+                                            (10, 0, 4), (129, 100, 260), (125, 4096, 512), (40, 2048, 96)])
 def test_linear(ga, cref, rows, fin, fout):
     from gwen_amd import ops
     gen = torch.Generator().manual_seed(SEED + rows + fin)

@@ -51,7 +51,7 @@ def main():
             t = timed(lambda: L.gwen_gcn_propagate_f32(_ptr(g.rowptr), _ptr(g.col), _ptr(g.val), _ptr(h), _ptr(b), _ptr(out), N, F, F, F, 1, N * F, N * F, 1, st))
             print(f"F={F:4d} K2 propagate {t:7.2f} us  {balg/t/1e6:6.2f} TB/s alg  {E/t/1e3:6.2f} Gedge/s")
         if which in ("k3", "all"):
-            t = timed(lambda: L.gwen_gcn_linear_f32(_ptr(h), _ptr(w), None, _ptr(out), N, F, F, F, F, 0, int(os.environ.get('KB_EXACT', '0')), st))
+            t = timed(lambda: L.gwen_gcn_linear_f32(_ptr(h), _ptr(w), None, _ptr(out), N, F, F, F, F, 0, int(os.environ.get('KB_EXACT', '0')), None, 0, st))
             print(f"F={F:4d} K3 linear    {t:7.2f} us  {2*N*F*F/t/1e6:6.2f} TFLOP/s  {(8*N*F)/t/1e6:5.2f} TB/s")
         if which in ("k4", "all") and L.gwen_gcn_layer_supported(F, F):
             t = timed(lambda: L.gwen_gcn_layer_f32(_ptr(gr), _ptr(gc), _ptr(gv), _ptr(h), _ptr(w), _ptr(b), _ptr(out), N, F, F, F, F, 1, N * F, N * F, 1, int(os.environ.get('KB_EXACT', '0')), st))
