@@ -169,11 +169,14 @@ def main():
     elapsed = float(elapsed.item())
     assert gathered.shape[0] == members and torch.isfinite(gathered).all()
 
+    # a bracket = kernel + one event record's worth of stream time: calibrate the latter on empty
+    # brackets and take it off (agrees with rocprofv3's kernel-only durations within 0.4 us)
+    ev_over = gwen_amd.event_bracket_overhead(dev)
     summ = {}
     for evs in ev_sets:
         for kind, layer, fin, fout, sec in evs.durations():
             cnt, tot = summ.get((kind, fin, fout), (0, 0.0))
-            summ[(kind, fin, fout)] = (cnt + 1, tot + sec)
+            summ[(kind, fin, fout)] = (cnt + 1, tot + max(sec - ev_over, 0.0))
 
     # ---- roofline of the dominant kernel (events recorded inside the timed region) ---------------
     dom_key = max(summ, key=lambda k: summ[k][1])
@@ -200,7 +203,7 @@ def main():
         "bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": round(avg_s * 1e6, 2),
-        "launches": launches,
+        "launches": launches, "event_record_overhead_us": round(ev_over * 1e6, 2),
         "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())},
     }
 

@@ -6,7 +6,7 @@ torch-geometric (:19).  Kernels live in libgwen_hip.so (include/gwen_hip.h); bui
 ``python -m gwen_amd.build``.
 """
 from . import ops
-from .forward import GraphedForward, KernelEvents, StackForward
+from .forward import GraphedForward, KernelEvents, StackForward, event_bracket_overhead
 from .gcn_conv import GCNConv, Linear
 from .graph import GraphCSR, GraphCache, default_cache, prepare_graph
 from .mesh import Mesh, complete_graph, geodesic_mesh
@@ -14,7 +14,7 @@ from .models_gnn import (DownConvLayers, GCNConvLayers, GNNConfig, GNNModel, UpC
                          loss_func)
 
 __all__ = [
-    "GCNConv", "Linear", "GraphedForward", "KernelEvents", "StackForward", "GraphCSR", "GraphCache", "default_cache", "prepare_graph", "Mesh",
+    "GCNConv", "Linear", "GraphedForward", "KernelEvents", "StackForward", "event_bracket_overhead", "GraphCSR", "GraphCache", "default_cache", "prepare_graph", "Mesh",
     "complete_graph", "geodesic_mesh", "DownConvLayers", "GCNConvLayers", "GNNConfig", "GNNModel",
     "UpConvLayers", "loss_func",
 ]

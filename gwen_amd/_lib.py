@@ -65,6 +65,7 @@ SIGNATURES = {
                                     C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]),
     "gwen_event_create": (_int, [C.POINTER(C.c_void_p)]),
     "gwen_event_destroy": (_int, [_vp]),
+    "gwen_event_record": (_int, [_vp, _vp]),
     "gwen_event_synchronize": (_int, [_vp]),
     "gwen_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "gwen_gcn_grad_workspace_floats": (_i64, [_i64, _i64, _i64]),

@@ -203,6 +203,11 @@ extern "C" int gwen_event_destroy(void *event) {
   GWEN_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
   return GWEN_OK;
 }
+extern "C" int gwen_event_record(void *event, gwen_stream_t stream) {
+  if (!event) return GWEN_EINVAL;
+  GWEN_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(event), gwen_stream(stream)));
+  return GWEN_OK;
+}
 extern "C" int gwen_event_synchronize(void *event) {
   if (!event) return GWEN_EINVAL;
   GWEN_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(event)));

@@ -65,6 +65,30 @@ class KernelEvents:
             pass
 
 
+def event_bracket_overhead(device, samples: int = 32) -> float:
+    """Seconds of stream time one hipEvent record costs, from empty brackets (two records back to back,
+    median over ``samples``, halved).  A bracket around a kernel contains one record's worth of it, so
+    ``bracket - overhead`` is the kernel-only time (checked against rocprofv3: within 0.4 us)."""
+    L = _lib.lib()
+    ev = KernelEvents(samples)
+    st = _stream(device)
+    with torch.cuda.device(device):
+        torch.cuda.synchronize(device)
+        for i in range(samples):
+            _lib.check(L.gwen_event_record(ev._ev[2 * i], st), "gwen_event_record")
+            _lib.check(L.gwen_event_record(ev._ev[2 * i + 1], st), "gwen_event_record")
+        torch.cuda.synchronize(device)
+    ms = C.c_float(0)
+    vals = []
+    for i in range(samples):
+        _lib.check(L.gwen_event_elapsed_ms(ev._ev[2 * i], ev._ev[2 * i + 1], C.byref(ms)),
+                   "gwen_event_elapsed_ms")
+        vals.append(ms.value * 1e-3)
+    ev.close()
+    vals.sort()
+    return 0.5 * vals[len(vals) // 2]
+
+
 class StackForward:
     """A stack of GCN layers bound to one prepared graph: ``run(x)`` is one C call."""
 

@@ -194,6 +194,7 @@ int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float 
  * stream the kernels are launched on). */
 int gwen_event_create(void **event /* host out */);
 int gwen_event_destroy(void *event);
+int gwen_event_record(void *event, gwen_stream_t stream);
 int gwen_event_synchronize(void *event);
 int gwen_event_elapsed_ms(void *start, void *stop, float *ms /* host out */);
 
