@@ -5,7 +5,7 @@ UpConvLayers, GCNConvLayers, GNNModel, loss_func) plus the ``GCNConv`` layer it 
 torch-geometric (:19).  Kernels live in libgwen_hip.so (include/gwen_hip.h); build it with
 ``python -m gwen_amd.build``.
 """
-from . import ops
+from . import g2m, ops
 from .forward import GraphedForward, KernelEvents, StackForward, event_bracket_overhead
 from .gcn_conv import GCNConv, Linear
 from .graph import GraphCSR, GraphCache, default_cache, prepare_graph

@@ -45,6 +45,8 @@ SIGNATURES = {
     "gwen_gcn_prep_workspace_bytes": (_int, [_i64, _i64, C.POINTER(C.c_size_t)]),
     "gwen_gcn_prep": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, C.c_size_t, _vp]),
+    "gwen_gcn_prep_rect": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  C.c_size_t, _vp]),
     "gwen_gcn_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gwen_gcn_group8_capacity": (_i64, [_i64, _i64]),
     "gwen_gcn_group8": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),

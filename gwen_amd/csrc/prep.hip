@@ -34,14 +34,14 @@ __global__ void k_init(int32_t *loop_last, int64_t N, int32_t *status) {
 
 // key = (target << ebits) | e for kept edges; dropped edges (explicit loops when loops are being
 // completed, out-of-range indices) get target = N so they sort behind every row.
-__global__ void k_mark(const int64_t *__restrict__ ei, int64_t N, int64_t E, int add_loops,
-                       int ebits, uint64_t *__restrict__ keys, int32_t *__restrict__ loop_last,
-                       int32_t *__restrict__ status) {
+__global__ void k_mark(const int64_t *__restrict__ ei, int64_t Nsrc, int64_t N, int64_t E,
+                       int add_loops, int ebits, uint64_t *__restrict__ keys,
+                       int32_t *__restrict__ loop_last, int32_t *__restrict__ status) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= E) return;
   int64_t s = ei[e], d = ei[E + e];
   uint64_t tgt;
-  if (s < 0 || s >= N || d < 0 || d >= N) {
+  if (s < 0 || s >= Nsrc || d < 0 || d >= N) {
     atomicOr(status, 1);
     tgt = (uint64_t)N;
   } else if (add_loops && s == d) {
@@ -124,6 +124,16 @@ __global__ void k_norm(const int32_t *__restrict__ rowptr, const int32_t *__rest
   float dd = dis[r];
   for (int32_t p = rowptr[r] + lane, e = rowptr[r + 1]; p < e; p += 8)
     val[p] = (dis[col[p]] * val[p]) * dd;
+}
+
+// mean aggregation of a rectangular (bipartite) graph: val /= sum of the row's raw weights
+__global__ void k_rowmean(const int32_t *__restrict__ rowptr, int64_t N, float *__restrict__ val) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const int32_t p0 = rowptr[r], p1 = rowptr[r + 1];
+  float s = 0.0f;
+  for (int32_t p = p0; p < p1; ++p) s = s + val[p];
+  for (int32_t p = p0; p < p1; ++p) val[p] = val[p] / s;
 }
 
 // ---- transpose ------------------------------------------------------------------------------
@@ -258,7 +268,7 @@ extern "C" int gwen_gcn_prep(const int64_t *edge_index, const float *edge_weight
   GWEN_LAUNCH_CHECK();
   const uint64_t *ks = keys_in;
   if (E > 0) {
-    k_mark<<<blocks_for(E), kThreads, 0, stream>>>(edge_index, N, E, add_self_loops, ebits,
+    k_mark<<<blocks_for(E), kThreads, 0, stream>>>(edge_index, N, N, E, add_self_loops, ebits,
                                                    keys_in, loop_last, status);
     GWEN_LAUNCH_CHECK();
     size_t tb = L.temp_bytes;
@@ -284,6 +294,52 @@ extern "C" int gwen_gcn_prep(const int64_t *edge_index, const float *edge_weight
       k_deg<<<blocks_for(N), kThreads, 0, stream>>>(rowptr, val, N, dis);
       GWEN_LAUNCH_CHECK();
       k_norm<<<blocks_for(N * 8), kThreads, 0, stream>>>(rowptr, col, dis, N, val);
+      GWEN_LAUNCH_CHECK();
+    }
+  }
+  return GWEN_OK;
+}
+
+extern "C" int gwen_gcn_prep_rect(const int64_t *edge_index, const float *edge_weight,
+                                  int64_t N_src, int64_t N_dst, int64_t E, int mean,
+                                  int32_t *rowptr, int32_t *col, float *val, int32_t *eid,
+                                  int32_t *status, void *workspace, size_t workspace_bytes,
+                                  gwen_stream_t stream_) {
+  if (N_src < 0 || N_dst < 0 || E < 0 || !rowptr || !status || (E > 0 && !edge_index))
+    return GWEN_EINVAL;
+  if (N_src + E >= (int64_t(1) << 31) - 1 || N_dst + E >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
+  if (E > 0 && (!col || !val || !eid)) return GWEN_EINVAL;
+  WsLayout L;
+  int rc = ws_layout(N_dst, E, &L);
+  if (rc != GWEN_OK) return rc;
+  if (!workspace || workspace_bytes < L.total) return GWEN_ENOSPACE;
+  hipStream_t stream = gwen_stream(stream_);
+  char *ws = static_cast<char *>(workspace);
+  uint64_t *keys_in = reinterpret_cast<uint64_t *>(ws + L.keys_in);
+  uint64_t *keys_out = reinterpret_cast<uint64_t *>(ws + L.keys_out);
+  int32_t *loop_last = reinterpret_cast<int32_t *>(ws + L.loop_last);
+  const int ebits = bits_for((uint64_t)(E > 1 ? E : 2));
+  const int nbits = bits_for((uint64_t)N_dst + 1);
+  k_init<<<blocks_for(N_dst > 0 ? N_dst : 1), kThreads, 0, stream>>>(loop_last, N_dst, status);
+  GWEN_LAUNCH_CHECK();
+  const uint64_t *ks = keys_in;
+  if (E > 0) {
+    k_mark<<<blocks_for(E), kThreads, 0, stream>>>(edge_index, N_src, N_dst, E, 0, ebits, keys_in,
+                                                   loop_last, status);
+    GWEN_LAUNCH_CHECK();
+    size_t tb = L.temp_bytes;
+    GWEN_HIP_CHECK(rocprim::radix_sort_keys(ws + L.temp, tb, keys_in, keys_out, (size_t)E, 0u,
+                                            (unsigned)(ebits + nbits), stream));
+    ks = keys_out;
+  }
+  k_rowptr<<<blocks_for(N_dst + 1), kThreads, 0, stream>>>(ks, E, N_dst, ebits, 0, rowptr, status);
+  GWEN_LAUNCH_CHECK();
+  if (E > 0) {
+    k_fill<<<blocks_for(E), kThreads, 0, stream>>>(ks, edge_index, edge_weight, E, N_dst, ebits, 0,
+                                                   col, val, eid);
+    GWEN_LAUNCH_CHECK();
+    if (mean && N_dst > 0) {
+      k_rowmean<<<blocks_for(N_dst), kThreads, 0, stream>>>(rowptr, N_dst, val);
       GWEN_LAUNCH_CHECK();
     }
   }

@@ -42,6 +42,7 @@ class GraphCSR:
     eid: Tensor                    # int32 [E+N]   original edge id, -1 for a completed loop
     dis: Tensor                    # fp32  [N]     deg^-1/2
     status: Tensor                 # int32 [2]     [bad-index flag, E']
+    num_src: int = -1              # source-node count; -1: square graph (== num_nodes)
     _workspace: Optional[Tensor] = field(default=None, repr=False)
     _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
     _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
@@ -49,6 +50,10 @@ class GraphCSR:
     @property
     def device(self) -> torch.device:
         return self.rowptr.device
+
+    @property
+    def source_nodes(self) -> int:
+        return self.num_nodes if self.num_src < 0 else self.num_src
 
     def nnz(self) -> int:
         """Number of stored entries E' (synchronises)."""
@@ -63,6 +68,8 @@ class GraphCSR:
 
     def transposed(self) -> Tuple[Tensor, Tensor, Tensor]:
         """CSR by SOURCE node (rowptr, col = target, val) for the backward pass; built on first use."""
+        if self.num_src >= 0:
+            raise RuntimeError("bipartite graphs are inference-only (no transposed structure)")
         if self._transposed is None:
             n, cap = self.num_nodes, self.num_nodes + self.num_edges
             dev = self.device
@@ -160,6 +167,40 @@ def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tens
     g = GraphCSR(n, e, rowptr, col, val, eid, dis, status, _workspace=ws)
     if validate and int(status[0].item()) != 0:
         raise IndexError(f"edge_index holds node indices outside [0, {n})")
+    return g
+
+
+def prepare_bipartite(edge_index: Tensor, num_src: int, num_dst: int,
+                      edge_weight: Optional[Tensor] = None, *, mean: bool = True,
+                      validate: bool = True) -> GraphCSR:
+    """Rectangular graph (sources -> targets, no self-loops) for the grid<->mesh maps of SURVEY 8(f) f2.
+    BUILD-DEFINED (the reference has no bipartite graphs): ``mean=True`` normalises each target's
+    in-edge weights to sum to one.  The result plugs into the same propagate / fused-layer kernels;
+    features of the source set have ``num_src`` rows, outputs ``num_dst`` rows."""
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError("edge_index must be int64 [2, E]")
+    if not edge_index.is_cuda:
+        raise RuntimeError("gwen_amd needs edge_index on a HIP device; there is no CPU fallback")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    e = ei.size(1)
+    ew = None if edge_weight is None else edge_weight.detach().to(torch.float32).contiguous()
+    cap = max(e + num_dst, 1) + 8
+    rowptr = torch.empty(num_dst + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(cap, dtype=torch.int32, device=dev)
+    val = torch.empty(cap, dtype=torch.float32, device=dev)
+    eid = torch.empty(cap, dtype=torch.int32, device=dev)
+    status = torch.empty(2, dtype=torch.int32, device=dev)
+    ws = _alloc_workspace(num_dst, e, dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_prep_rect(_ptr(ei), _ptr(ew), num_src, num_dst, e, int(mean),
+                                           _ptr(rowptr), _ptr(col), _ptr(val), _ptr(eid), _ptr(status),
+                                           _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(rc, "gwen_gcn_prep_rect")
+    g = GraphCSR(num_dst, e, rowptr, col, val, eid, torch.empty(1, device=dev), status, num_src=num_src,
+                 _workspace=ws)
+    if validate and int(status[0].item()) != 0:
+        raise IndexError("edge_index holds node indices outside the source / target ranges")
     return g
 
 

@@ -37,9 +37,10 @@ def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: b
     """K2: out[i] = act(sum_s val[s] * h[col[s]] + bias) over the CSR (or its transpose)."""
     _require(h, "h")
     h = h.contiguous()
-    m, n, f = _rows2d(h)
-    if n != graph.num_nodes:
-        raise ValueError(f"h has {n} rows but the graph has {graph.num_nodes} nodes")
+    m, n_src, f = _rows2d(h)
+    n = graph.num_nodes
+    if n_src != graph.source_nodes:
+        raise ValueError(f"h has {n_src} rows but the graph has {graph.source_nodes} source nodes")
     if transposed:
         rowptr, col, val = graph.transposed()
     else:
@@ -47,12 +48,12 @@ def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: b
     if bias is not None:
         _require(bias, "bias")
         bias = bias.contiguous()
-    out = torch.empty_like(h)
+    out = torch.empty(*h.shape[:-2], n, f, dtype=torch.float32, device=h.device)
     dev = h.device
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_propagate_f32(
             _ptr(rowptr), _ptr(col), _ptr(val), _ptr(h), _ptr(bias), _ptr(out), n, f, f, f, m,
-            n * f, n * f, int(relu), _stream(dev))
+            n_src * f, n * f, int(relu), _stream(dev))
     _lib.check(rc, "gwen_gcn_propagate_f32")
     return out
 
@@ -99,20 +100,23 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     _require(weight, "weight")
     x = x.contiguous()
     weight = weight.contiguous()
-    m, n, fin = _rows2d(x)
+    m, n_src, fin = _rows2d(x)
+    n = graph.num_nodes
     fout = weight.size(0)
-    if n != graph.num_nodes or weight.size(1) != fin:
+    if n_src != graph.source_nodes or weight.size(1) != fin:
         raise ValueError("shape mismatch between x, weight and the graph")
+    if n_src * fin * 4 >= (1 << 32):
+        raise ValueError("x is too large for K4's 32-bit row offsets")
     if bias is not None:
         _require(bias, "bias")
         bias = bias.contiguous()
-    out = torch.empty(*x.shape[:-1], fout, dtype=torch.float32, device=x.device)
+    out = torch.empty(*x.shape[:-2], n, fout, dtype=torch.float32, device=x.device)
     dev = x.device
     g_rowptr, g_col, g_val = graph.grouped()
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_layer_f32(
             _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(weight), _ptr(bias),
-            _ptr(out), n, fin, fout, fin, fout, m, n * fin, n * fout, int(relu), int(exact),
+            _ptr(out), n, fin, fout, fin, fout, m, n_src * fin, n * fout, int(relu), int(exact),
             _stream(dev))
     _lib.check(rc, "gwen_gcn_layer_f32")
     return out

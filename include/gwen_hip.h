@@ -58,6 +58,16 @@ int gwen_gcn_prep(const int64_t *edge_index, const float *edge_weight, int64_t N
                   int32_t *col, float *val, int32_t *eid, float *dis, int32_t *status,
                   void *workspace, size_t workspace_bytes, gwen_stream_t stream);
 
+/* Rectangular (bipartite) graph for the grid->mesh / mesh->grid maps of SURVEY 8(f) f2 (BUILD-DEFINED:
+ * the reference has no such graphs): edges run from N_src source nodes to N_dst target
+ * nodes, no self-loops; CSR by target as above with rowptr [N_dst+1].  mean = 1: val = w / (sum of the
+ * row's weights) (mean aggregation); mean = 0: val = w.  K2/K4 take it as is (x has N_src rows).
+ * workspace: gwen_gcn_prep_workspace_bytes(N_dst, E). */
+int gwen_gcn_prep_rect(const int64_t *edge_index, const float *edge_weight, int64_t N_src,
+                       int64_t N_dst, int64_t E, int mean, int32_t *rowptr, int32_t *col, float *val,
+                       int32_t *eid, int32_t *status, void *workspace, size_t workspace_bytes,
+                       gwen_stream_t stream);
+
 /* Transposed structure (CSR by SOURCE) of a prepared graph, for the backward pass
  * (grad_h = A~^T grad_out).  Same value array semantics; rows keep target order ascending.
  * workspace: same size as for gwen_gcn_prep with E := rowptr[N] upper bound (E + N). */
