@@ -89,7 +89,6 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   const int nb = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nb >> 3, r8 = nb & 7;
   const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int b0 = lb * C::BR;
 
   const char *xb = reinterpret_cast<const char *>(x + (int64_t)blockIdx.y * mstride_x);
   float *om = out + (int64_t)blockIdx.y * mstride_o;
@@ -121,6 +120,14 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   float4_t bv4 = {0.f, 0.f, 0.f, 0.f};
   if (bias) bv4 = *reinterpret_cast<const float4_t *>(bias + j * 16 + 4 * mh);
 
+  // A block walks chunks lb, lb + grid, ... of BR rows: with one chunk per block (narrow layers) the
+  // loop runs once; wide layers launch one resident set of blocks so that W -- fetched and split into
+  // this wave's registers once, above -- serves many chunks (at 256 channels W is half as many bytes
+  // as a 64-row chunk gathers)
+  constexpr bool kPersist = FIN * FOUT >= 128 * 128;
+  const int nchunks = kPersist ? (N + C::BR - 1) / C::BR : lb + 1;
+  for (int chunk = lb; chunk < nchunks; chunk += nb) {
+  const int b0 = chunk * C::BR;
   // ---- phase 1: gather + aggregate into the LDS tile (gather_rows.h) ------------------------------
   gwen::gather_passes<FIN, C::NP, C::RB, UNI>(
       rowptr, col, val, xb, N, b0, wave, gr, lane_off, [&](int lr, float4_t acc) {
@@ -176,6 +183,8 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
     }
     if (r < N) *reinterpret_cast<float4_t *>(om + (int64_t)r * ldo + j * 16 + 4 * mh) = o;
   }
+  if constexpr (kPersist) __syncthreads();     // the tile is free for the next chunk
+  }
 }
 
 template <int FIN, int FOUT, bool SPLIT>
@@ -185,7 +194,18 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
   // rows per block: enough that W (read once per block) stays a small fraction of the gathered bytes
   constexpr int BRMIN = FIN == 128 ? 128 : 64;     // 256: 64 rows keep two blocks per CU in LDS
   using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
-  const int64_t blocks = (N + C::BR - 1) / C::BR;
+  int64_t blocks = (N + C::BR - 1) / C::BR;
+  if (FIN * FOUT >= 128 * 128) {       // wide layer: one resident set of blocks, W fetched once each
+    static int per_cu = 0;
+    if (per_cu == 0) {
+      int nbk = 0;
+      GWEN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nbk, reinterpret_cast<const void *>(&k_layer<FIN, FOUT, SPLIT, BRMIN, true>), C::NWB * 64, 0));
+      per_cu = nbk < 1 ? 1 : nbk;
+    }
+    const int64_t resident = (int64_t)256 * per_cu;
+    if (blocks > resident) blocks = resident;
+  }
   dim3 grid((unsigned)blocks, (unsigned)members);
   if (!rowptr)      // uniform layout: row r is the group at 8 r
     k_layer<FIN, FOUT, SPLIT, BRMIN, true><<<grid, C::NWB * 64, 0, st>>>(
