@@ -256,11 +256,20 @@ constexpr bool width_ok(int64_t f) { return f == 16 || f == 32 || f == 64 || f =
 
 }  // namespace
 
+// LDS of one block (bytes), as Cfg computes it; the chained form keeps two hi/lo images
+inline int64_t chain_lds_bytes(int64_t Fin, int64_t F1, int64_t F2) {
+  const int64_t R = 64 / (Fin / 4), nwb = F1 / 16 > 4 ? 8 : 4, rb = nwb * R;
+  const int64_t brmin = Fin >= 128 ? 128 : 64, br = rb > brmin ? rb : brmin;
+  return 2 * br * pitch_bf16((int)Fin) * 2 + (F2 > 0 ? 2 * br * pitch_bf16((int)F1) * 2 : 0);
+}
+
 extern "C" int gwen_gcn_chain_supported(int64_t Fin, int64_t F1, int64_t F2, int pre) {
   if (pre && F1 == 0 && F2 == 0) return width_ok(Fin) ? 1 : 0;      // activation-first, nothing chained
   if (!width_ok(Fin) || !width_ok(F1)) return 0;
   if (pre) return F2 == 0 ? 1 : 0;
-  return (width_ok(F2) && F2 < F1) ? 1 : 0;          // chained projection of a SHRINKING next layer
+  if (!(width_ok(F2) && F2 < F1)) return 0;          // chained projection of a SHRINKING next layer
+  // worth it only while two blocks still fit a CU's 160 KiB of LDS (otherwise K4, then K3 + K2)
+  return chain_lds_bytes(Fin, F1, F2) <= 80 * 1024 ? 1 : 0;
 }
 
 extern "C" int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *val,
