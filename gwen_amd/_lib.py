@@ -35,6 +35,7 @@ class LaunchInfo(C.Structure):
 
 ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
 KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN = 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer",
               KIND_CHAIN: "chain"}
 
@@ -74,6 +75,11 @@ SIGNATURES = {
     "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "gwen_relu_backward_f32": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gwen_mlp2_supported": (_int, [_i64]),
+    "gwen_edge_tiles_count": (_i64, [_i64, _i64]),
+    "gwen_edge_tiles": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "gwen_mlp2_f32": (_int, [_vp] * 4 + [_i64, _vp, _vp, _i64] + [_vp] * 5 + [_i64, _i64, _int, _vp, _vp, _i64,
+                              _vp, _i64, _int, _vp]),
 }
 
 

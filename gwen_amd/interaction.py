@@ -1,0 +1,164 @@
+"""InteractionNet block on the K6 kernel (BASELINE north_star "edge-MLP + scatter-add").
+
+BUILD-DEFINED -- the reference's only graph layer is GCNConv (/root/reference/src/gwen/models_gnn.py:
+118-130,:147-149); it has no edge features and no edge MLP.  Semantics (restated on the CPU by
+oracle/interaction_oracle.py, PARITY UNPINNED):
+
+    m_e   = MLP_e([e, x_src[s(e)], x_dst[d(e)]])          MLP = Linear -> act -> Linear
+    agg_d = sum / mean of m_e over the in-edges of d
+    x'_d  = x_dst_d + MLP_n([x_dst_d, agg_d]) ,   e' = e + m_e
+
+How it runs (5 launches, inference only):
+  * the node halves of both first layers are projected per NODE, not per edge (K3, 3xbf16):
+    Ps = x_src W1[:, F:2F]^T,  Pd = x_dst W1[:, 2F:]^T + b1,  Q = x_dst W3[:, :F]^T + b3;
+  * K6 over edges (target-sorted):  e' and agg in one launch -- gathers Ps[s], Pd[d], never forms the
+    [E,3F] concatenation, the hidden layer or the message tensor in HBM;
+  * K6 over nodes:  x' = x_dst + act(agg W3[:, F:]^T + Q) W4^T + b4.
+Edge features live in the graph's STORED order (targets ascending): ``EdgeGraph.sort_edges`` /
+``unsort_edges`` convert from / to the order of the ``edge_index`` the graph was built from.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib, ops
+from .graph import GraphCSR, _ptr, _stream, prepare_bipartite
+
+_ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "silu": _lib.ACT_SILU}
+_ROWS = 64          # rows per K6 pass
+
+
+@dataclass
+class EdgeGraph:
+    """Target-sorted edge list + the row-aligned tiling K6 walks (include/gwen_hip.h, gwen_edge_tiles)."""
+
+    num_src: int
+    num_dst: int
+    num_edges: int
+    rowptr: Tensor        # int32 [num_dst + 1]
+    src: Tensor           # int32 [E]  source node of stored edge k
+    dst: Tensor           # int32 [E]  target node of stored edge k
+    eid: Tensor           # int32 [E]  position of stored edge k in the edge_index it came from
+    tile_row: Tensor      # int32 [n_tiles + 1]
+    n_tiles: int
+
+    @property
+    def device(self) -> torch.device:
+        return self.rowptr.device
+
+    def sort_edges(self, e: Tensor) -> Tensor:
+        """Edge features in ``edge_index`` order -> stored order."""
+        return e.index_select(0, self.eid.long())
+
+    def unsort_edges(self, e: Tensor) -> Tensor:
+        out = torch.empty_like(e)
+        out.index_copy_(0, self.eid.long(), e)
+        return out
+
+
+def interaction_graph(edge_index: Tensor, num_src: int, num_dst: int) -> EdgeGraph:
+    """Once per graph: sort by target (K1, gwen_gcn_prep_rect) and tile (gwen_edge_tiles)."""
+    g: GraphCSR = prepare_bipartite(edge_index, num_src, num_dst, mean=False)
+    e, dev = g.num_edges, g.device
+    # one read-back per graph: the longest row decides the tile size (a tile = one 64-row pass)
+    max_deg = int((g.rowptr[1:] - g.rowptr[:-1]).max().item()) if num_dst > 0 else 0
+    t = max(_ROWS - max(max_deg - 1, 0), _ROWS // 2) if max_deg <= _ROWS else _ROWS
+    n_tiles = int(_lib.lib().gwen_edge_tiles_count(e, t))
+    tile_row = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    dst = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_edge_tiles(_ptr(g.rowptr), num_dst, e, t, _ptr(tile_row), _ptr(dst),
+                                        _stream(dev))
+    _lib.check(rc, "gwen_edge_tiles")
+    return EdgeGraph(num_src, num_dst, e, g.rowptr, g.col[:e], dst[:e], g.eid[:e], tile_row, n_tiles)
+
+
+def mlp2_supported(channels: int) -> bool:
+    return bool(_lib.lib().gwen_mlp2_supported(channels))
+
+
+def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
+         g1: Optional[Tensor] = None, idx1: Optional[Tensor] = None, g2: Optional[Tensor] = None,
+         idx2: Optional[Tensor] = None, b1: Optional[Tensor] = None, res: Optional[Tensor] = None,
+         act: str = "silu", graph: Optional[EdgeGraph] = None, mean: bool = False,
+         want_out: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """K6 (gwen_mlp2_f32): returns (out, agg); ``agg`` only with ``graph`` (rows = its stored edges)."""
+    f = a.size(-1)
+    if a.dim() != 2 or not mlp2_supported(f):
+        raise ValueError(f"K6 needs [rows, F] with F in (32, 64, 128); got {tuple(a.shape)}")
+    if tuple(w1.shape) != (f, f) or tuple(w2.shape) != (f, f):
+        raise ValueError("W1 and W2 must be [F, F]")
+    ts = {"a": a, "w1": w1, "w2": w2, "b1": b1, "b2": b2, "g1": g1, "g2": g2, "res": res}
+    for name, t in ts.items():
+        if t is not None:
+            ops._require(t, name)
+            ts[name] = t.contiguous()
+    a, w1, w2, b1, b2, g1, g2, res = (ts[k] for k in ("a", "w1", "w2", "b1", "b2", "g1", "g2", "res"))
+    rows = a.size(0)
+    for name, idx, g in (("idx1", idx1, g1), ("idx2", idx2, g2)):
+        if idx is not None and (g is None or idx.dtype != torch.int32 or idx.numel() != rows):
+            raise ValueError(f"{name} must be int32 [rows] and come with its table")
+        if idx is None and g is not None and g.size(0) != rows:
+            raise ValueError("a table without an index must have one row per row of A")
+    if res is not None and res.shape != a.shape:
+        raise ValueError("res must have the shape of A")
+    dev = a.device
+    out = torch.empty_like(a) if want_out else None
+    agg = None
+    if graph is not None:
+        if graph.num_edges != rows:
+            raise ValueError("A must hold one row per stored edge of the graph")
+        agg = torch.empty(graph.num_dst, f, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_mlp2_f32(
+            _ptr(a), _ptr(w1), _ptr(g1), _ptr(idx1), 0 if g1 is None else g1.size(0),
+            _ptr(g2), _ptr(idx2), 0 if g2 is None else g2.size(0), _ptr(b1), _ptr(w2), _ptr(b2),
+            _ptr(res), _ptr(out), rows, f, _ACT[act],
+            _ptr(graph.rowptr) if graph else None, _ptr(graph.tile_row) if graph else None,
+            graph.n_tiles if graph else 0, _ptr(agg), graph.num_dst if graph else 0, int(mean),
+            _stream(dev))
+    _lib.check(rc, "gwen_mlp2_f32")
+    return out, agg
+
+
+def _mlp(fin: int, f: int, act: str) -> nn.Sequential:
+    a = {"none": nn.Identity, "relu": nn.ReLU, "silu": nn.SiLU}[act]()
+    return nn.Sequential(nn.Linear(fin, f), a, nn.Linear(f, f))
+
+
+class InteractionNet(nn.Module):
+    """``forward(x_src, x_dst, e, graph) -> (x_dst', e')``; parameters ``edge_mlp.{0,2}.{weight,bias}``
+    ([F,3F] / [F,F]) and ``node_mlp.{0,2}.{weight,bias}`` ([F,2F] / [F,F]).  Inference only."""
+
+    def __init__(self, channels: int, activation: str = "silu", aggr: str = "sum"):
+        super().__init__()
+        if activation not in _ACT or aggr not in ("sum", "mean"):
+            raise ValueError("activation in (none, relu, silu), aggr in (sum, mean)")
+        self.channels, self.activation, self.aggr = channels, activation, aggr
+        self.edge_mlp = _mlp(3 * channels, channels, activation)
+        self.node_mlp = _mlp(2 * channels, channels, activation)
+
+    def forward(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph,
+                update_edges: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (x_src, x_dst, e, *self.parameters())):
+            raise RuntimeError("InteractionNet is inference-only: call it under torch.no_grad()")
+        f = self.channels
+        if x_src.shape != (graph.num_src, f) or x_dst.shape != (graph.num_dst, f) or \
+                e.shape != (graph.num_edges, f):
+            raise ValueError("x_src / x_dst / e do not match the graph and the channel count")
+        w1, b1 = self.edge_mlp[0].weight, self.edge_mlp[0].bias
+        w3, b3 = self.node_mlp[0].weight, self.node_mlp[0].bias
+        ps = ops.linear(x_src, w1[:, f:2 * f], None, exact=False)
+        pd = ops.linear(x_dst, w1[:, 2 * f:], b1, exact=False)
+        e_new, agg = mlp2(e, w1[:, :f], self.edge_mlp[2].weight, self.edge_mlp[2].bias,
+                          g1=ps, idx1=graph.src, g2=pd, idx2=graph.dst, res=e, act=self.activation,
+                          graph=graph, mean=self.aggr == "mean", want_out=update_edges)
+        q = ops.linear(x_dst, w3[:, :f], b3, exact=False)
+        x_new, _ = mlp2(agg, w3[:, f:], self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
+                        res=x_dst, act=self.activation)
+        return x_new, e_new

@@ -225,6 +225,44 @@ int gwen_gcn_grad_bias_f32(const float *g, float *grad_b, int64_t rows, int64_t 
 int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t count,
                            gwen_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K6 -- InteractionNet block: edge MLP + sum to target nodes, and the node MLP  (SURVEY 8(f) f2).
+ * BUILD-DEFINED: the reference has no edge MLP (its layers are the GCNConv calls at
+ * /root/reference/src/gwen/models_gnn.py:147-149,:204-206); BASELINE.json's north_star names the
+ * block, semantics follow the published Interaction Network formulation restated in
+ * oracle/interaction_oracle.py (PARITY UNPINNED).
+ *
+ * gwen_mlp2_f32, for rows r = 0 .. R-1 of width F (gwen_mlp2_supported):
+ *     pre[r] = A[r] W1^T + G1[idx1 ? idx1[r] : r] + G2[idx2 ? idx2[r] : r] + b1    (G1, G2 optional)
+ *     y[r]   = act(pre[r]) W2^T + b2                       act: GWEN_ACT_NONE / RELU / SILU
+ *     out[r] = res[r] + y[r]                               (out, res optional; out may alias A / res)
+ *     agg[d] = sum (or mean) of y[r] over rows r with rowptr[d] <= r < rowptr[d+1]   (agg optional)
+ *   A, G*, res, out: fp32 row-major, contiguous rows of F; W1, W2: [F,F] row-major [out,in].
+ *   G1 / G2 have G1_rows / G2_rows rows (rows * F * 4 < 2^32); supported table pairs: none; G1 alone
+ *   (with or without idx1); G1 and G2 both indexed.  GWEN_EINVAL otherwise.
+ *   With agg: rows are the stored entries of a target-sorted CSR (rowptr int32 [N_agg+1],
+ *   rowptr[N_agg] == R) and tile_row [n_tiles+1] comes from gwen_edge_tiles; every target row is
+ *   summed by one block in stored order (no atomics; rows without entries get 0).
+ *   The contractions use the 3xbf16 split (see gwen_gcn_layer_f32, exact = 0).
+ *
+ * gwen_edge_tiles: row-aligned tiling of a CSR's entries.  tile c owns the target rows whose first
+ *   entry lies in [cT, (c+1)T); n_tiles = gwen_edge_tiles_count(E, T) = max(1, ceil(E/T)); T <= 64
+ *   (T = 64 - (max row length - 1), at least 1, keeps each tile a single pass of the kernel).
+ *   Also writes dst[e] = target row of entry e (int32 [E]) -- idx2 of the edge MLP.
+ * ------------------------------------------------------------------------------------------- */
+#define GWEN_ACT_NONE 0
+#define GWEN_ACT_RELU 1
+#define GWEN_ACT_SILU 2
+int gwen_mlp2_supported(int64_t F);
+int64_t gwen_edge_tiles_count(int64_t E, int64_t T);
+int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int64_t T, int32_t *tile_row,
+                    int32_t *dst, gwen_stream_t stream);
+int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_t *idx1,
+                  int64_t G1_rows, const float *G2, const int32_t *idx2, int64_t G2_rows,
+                  const float *b1, const float *W2, const float *b2, const float *res, float *out,
+                  int64_t R, int64_t F, int act, const int32_t *rowptr, const int32_t *tile_row,
+                  int64_t n_tiles, float *agg, int64_t N_agg, int mean, gwen_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,171 @@
+"""SURVEY 8(f) f2 (BUILD-DEFINED, parity unpinned): K6 -- edge MLP + sum to targets + node MLP
+(gwen_mlp2_f32, gwen_edge_tiles) against oracle/interaction_oracle.py; fp32 tolerance 1e-4 relative,
+index structures bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import REL_TOL, SEED, random_multigraph, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ga(hip_lib):
+    import gwen_amd
+    return gwen_amd
+
+
+def _graphs(ga):
+    from gwen_amd import g2m
+    from gwen_amd.mesh import complete_graph
+    m = ga.geodesic_mesh(6)
+    a, b = g2m.grid_mesh_edges(m)
+    n, nf = m.num_nodes, m.faces.shape[0]
+    return {
+        "mesh": (n, n, torch.from_numpy(m.edge_index)),
+        "g2m": (nf, n, torch.from_numpy(a)),
+        "m2g": (n, nf, torch.from_numpy(b)),
+        "K125": (125, 125, torch.from_numpy(complete_graph(125))),       # rows longer than one pass
+        "multi": (300, 300, random_multigraph(300, 2000, self_loops=40, dup=100, isolate=7)),
+        "sparse": (50, 4000, random_multigraph(50, 300, seed=5)[:, :300] * torch.tensor([[1], [80]])),
+        "star": (200, 200, torch.stack([torch.arange(1, 200), torch.zeros(199, dtype=torch.long)])),
+        "empty": (5, 7, torch.zeros(2, 0, dtype=torch.long)),
+        "one_edge": (3, 3, torch.tensor([[2], [1]])),
+    }
+
+
+@pytest.mark.parametrize("name", ["mesh", "g2m", "m2g", "K125", "multi", "sparse", "star", "empty", "one_edge"])
+def test_edge_tiles_are_row_aligned(ga, name):
+    from gwen_amd.interaction import interaction_graph
+    ns, nd, ei = _graphs(ga)[name]
+    g = interaction_graph(ei.to(DEV), ns, nd)
+    rp = g.rowptr.cpu().numpy().astype(np.int64)
+    e = ei.size(1)
+    assert rp[0] == 0 and rp[-1] == e and g.num_edges == e
+    # stored order = stable sort by target; src/dst/eid describe the same edges
+    order = np.argsort(ei[1].numpy(), kind="stable")
+    assert np.array_equal(g.dst.cpu().numpy(), ei[1].numpy()[order])
+    eid = g.eid.cpu().numpy()
+    assert np.array_equal(np.sort(eid), np.arange(e))
+    assert np.array_equal(g.src.cpu().numpy(), ei[0].numpy()[eid])
+    assert np.array_equal(g.dst.cpu().numpy(), ei[1].numpy()[eid])
+    # tiles: contiguous row ranges covering every row once; tile c starts at the first row whose
+    # first edge is at or after c T
+    tr = g.tile_row.cpu().numpy()
+    assert tr[0] == 0 and tr[-1] == nd and np.all(np.diff(tr) >= 0) and len(tr) == g.n_tiles + 1
+    max_deg = int(np.diff(rp).max()) if nd else 0
+    spans = rp[tr[1:]] - rp[tr[:-1]]
+    if max_deg <= 33:
+        assert spans.max() <= 64                         # a tile is a single 64-row pass
+    x = torch.randn(e, 3)
+    assert torch.equal(g.unsort_edges(g.sort_edges(x.to(DEV))).cpu(), x)
+
+
+@pytest.mark.parametrize("F", [32, 64, 128])
+@pytest.mark.parametrize("rows", [1, 63, 64, 65, 1000])
+@pytest.mark.parametrize("act", ["none", "relu", "silu"])
+def test_row_mlp_vs_oracle(ga, F, rows, act):
+    from gwen_amd.interaction import mlp2
+    from oracle import interaction_oracle as IO
+    g = torch.Generator().manual_seed(SEED + F + rows)
+    a = torch.randn(rows, F, generator=g)
+    w1 = torch.randn(F, F, generator=g) / F ** 0.5
+    w2 = torch.randn(F, F, generator=g) / F ** 0.5
+    b1, b2 = torch.randn(F, generator=g), torch.randn(F, generator=g)
+    tab = torch.randn(17, F, generator=g)
+    idx = torch.randint(0, 17, (rows,), generator=g)
+    want = a + IO.act_fn(act)(a.double() @ w1.double().t() + tab[idx].double() + b1.double()) @ w2.double().t() + b2
+    got, agg = mlp2(a.to(DEV), w1.to(DEV), w2.to(DEV), b2.to(DEV), g1=tab.to(DEV),
+                    idx1=idx.to(torch.int32).to(DEV), b1=b1.to(DEV), res=a.to(DEV), act=act)
+    assert agg is None
+    assert rel_err(got, want) <= REL_TOL
+
+
+def _params(F, seed):
+    from gwen_amd.interaction import InteractionNet
+    torch.manual_seed(seed)
+    net = InteractionNet(F)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    return net
+
+
+@pytest.mark.parametrize("name", ["mesh", "g2m", "m2g", "K125", "multi", "sparse", "star", "empty", "one_edge"])
+@pytest.mark.parametrize("F,act,aggr", [(64, "silu", "sum"), (32, "relu", "mean"), (128, "silu", "sum")])
+def test_interaction_block_vs_oracle(ga, name, F, act, aggr):
+    from gwen_amd.interaction import InteractionNet, interaction_graph
+    from oracle import interaction_oracle as IO
+    ns, nd, ei = _graphs(ga)[name]
+    torch.manual_seed(SEED)
+    net = InteractionNet(F, act, aggr)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(SEED + 1)
+    xs = torch.randn(ns, F, generator=g)
+    xd = xs if name in ("mesh", "K125", "multi", "star", "one_edge") else torch.randn(nd, F, generator=g)
+    e = torch.randn(ei.size(1), F, generator=g)
+    sd = {k: v.double() for k, v in net.state_dict().items()}
+    want_x, want_e = IO.interaction(xs.double(), xd.double(), e.double(), ei, sd, act, aggr)
+    graph = interaction_graph(ei.to(DEV), ns, nd)
+    net = net.to(DEV)
+    with torch.no_grad():
+        got_x, got_e = net(xs.to(DEV), xd.to(DEV), graph.sort_edges(e.to(DEV)), graph)
+        again_x, again_e = net(xs.to(DEV), xd.to(DEV), graph.sort_edges(e.to(DEV)), graph)
+    assert rel_err(got_x, want_x) <= REL_TOL
+    assert rel_err(graph.unsort_edges(got_e), want_e) <= REL_TOL
+    assert torch.equal(got_x, again_x) and torch.equal(got_e, again_e)        # no atomics anywhere
+
+
+def test_closed_forms(ga):
+    """Anchors that need no oracle: zero second layers leave the state untouched; targets without
+    in-edges receive an empty sum; the aggregate is the sum of the edge updates."""
+    from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
+    F = 64
+    ns, nd, ei = _graphs(ga)["sparse"]
+    graph = interaction_graph(ei.to(DEV), ns, nd)
+    net = _params(F, 3).to(DEV)
+    xs, xd = torch.randn(ns, F, device=DEV), torch.randn(nd, F, device=DEV)
+    e = torch.randn(graph.num_edges, F, device=DEV)
+    with torch.no_grad():
+        net.edge_mlp[2].weight.zero_(); net.edge_mlp[2].bias.zero_()
+        net.node_mlp[2].weight.zero_(); net.node_mlp[2].bias.zero_()
+        x1, e1 = net(xs, xd, e, graph)
+    assert torch.equal(x1, xd) and torch.equal(e1, e)
+    # agg == segmented sum of (e' - e), and rows without in-edges are exactly zero
+    net = _params(F, 4).to(DEV)
+    with torch.no_grad():
+        w1 = net.edge_mlp[0].weight
+        out, agg = mlp2(e, w1[:, :F], net.edge_mlp[2].weight, net.edge_mlp[2].bias, act="silu",
+                        graph=graph)
+    m = out.double().cpu()
+    want = torch.zeros(nd, F, dtype=torch.float64).index_add_(0, graph.dst.long().cpu(), m)
+    assert rel_err(agg, want) <= 1e-6
+    deg = np.diff(graph.rowptr.cpu().numpy())
+    assert (deg == 0).sum() > 0
+    assert torch.count_nonzero(agg[torch.from_numpy(deg == 0).to(DEV)]) == 0
+
+
+def test_rejects_misuse(ga):
+    from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
+    a = torch.randn(10, 48, device=DEV)
+    with pytest.raises(ValueError):
+        mlp2(a, torch.randn(48, 48, device=DEV), torch.randn(48, 48, device=DEV))
+    a = torch.randn(10, 64, device=DEV)
+    w = torch.randn(64, 64, device=DEV)
+    with pytest.raises(ValueError):
+        mlp2(a, w, w, g1=torch.randn(5, 64, device=DEV))
+    with pytest.raises(ValueError):
+        mlp2(a, w, w, g1=torch.randn(5, 64, device=DEV), idx1=torch.zeros(10, dtype=torch.int64, device=DEV))
+    ns, nd, ei = _graphs(ga)["one_edge"]
+    graph = interaction_graph(ei.to(DEV), ns, nd)
+    net = InteractionNet(64).to(DEV)
+    with pytest.raises(RuntimeError):
+        net(torch.randn(3, 64, device=DEV), torch.randn(3, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
+    with torch.no_grad(), pytest.raises(ValueError):
+        net(torch.randn(4, 64, device=DEV), torch.randn(3, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
