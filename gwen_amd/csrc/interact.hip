@@ -36,16 +36,25 @@ constexpr int kRows = 64;                 // rows per pass (4 MFMA row tiles)
 template <int F>
 struct MCfg {
   static constexpr int NJ = F / 16;                              // 16-column output tiles
-  static constexpr int NWB = NJ > 8 ? 16 : (NJ > 4 ? 8 : 4);     // waves per block
   static constexpr int NT = kRows / 16;
-  static constexpr int TSTEP = NWB / NJ;                         // row tiles strided over spare waves
+  // every column tile is shared by TSTEP waves (each takes every TSTEP-th row tile): 8 or 16 light
+  // waves per block instead of 4 heavy ones -- four waves per SIMD fit the register file
+  static constexpr int TSTEP = F == 32 ? 4 : (F == 64 ? 2 : 1);
+  static constexpr int NWB = NJ * TSTEP;                         // waves per block
+  static constexpr int MINW = F == 128 ? 2 : 4;                  // waves per SIMD to compile for
+  // F = 256: the two weight matrices as hi/lo fragments are 512 KB -- the whole register file of a
+  // CU -- so they cannot stay resident: they are pre-split once per launch into fragment-ordered bf16
+  // images (k_split_w) and every wave streams its slices from L2, one k-step ahead of the MFMAs
+  static constexpr bool STREAM = F > 128;
   static constexpr int TPW = NT / TSTEP;                         // row tiles per wave
   static constexpr int KS = F / 32;                              // k-steps of v_mfma_f32_16x16x32_bf16
   static constexpr int PB = ((F / 2) % 16 == 8 ? F / 2 : F / 2 + 8) * 2;   // hi/lo tile pitch (bf16)
   static constexpr int PY = F + 4;                               // y tile pitch (floats)
   static constexpr size_t split_bytes = (size_t)2 * kRows * PB * 2;
   static constexpr size_t y_bytes = (size_t)kRows * PY * 4;
-  static constexpr size_t lds_bytes = split_bytes > y_bytes ? split_bytes : y_bytes;
+  // two hi/lo images: the A tile (reused as the fp32 y tile of phase 4) and the hidden tile
+  static constexpr size_t a_bytes = split_bytes > y_bytes ? split_bytes : y_bytes;
+  static constexpr size_t lds_bytes = a_bytes + split_bytes;
   static constexpr int Q = F / 4;                                // 16-B pieces per row
   static constexpr int SLOTS = NWB * 64 / Q;                     // target rows reduced at a time
   static_assert(NT % TSTEP == 0, "row tiles must divide over the waves");
@@ -77,19 +86,86 @@ __device__ inline void load_w(const float *__restrict__ W, int j, int mi, int mh
   }
 }
 
+// TPW row tiles at once: the three products of a k-step go to TPW independent accumulators before
+// the next product touches the same one, so no MFMA waits for the one issued just before it
 template <int F>
-__device__ inline f32x4 tile_mma(const __bf16 *thi, const __bf16 *tlo, int arow, int mh,
-                                 const bf16x8 (&whi)[MCfg<F>::KS], const bf16x8 (&wlo)[MCfg<F>::KS]) {
-  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+__device__ inline void tiles_mma(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh,
+                                 const bf16x8 (&whi)[MCfg<F>::KS], const bf16x8 (&wlo)[MCfg<F>::KS],
+                                 f32x4 (&d)[MCfg<F>::TPW]) {
+  using C = MCfg<F>;
 #pragma unroll
-  for (int ks = 0; ks < MCfg<F>::KS; ++ks) {
-    const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(thi + arow + 8 * (4 * ks + mh));
-    const bf16x8 alo = *reinterpret_cast<const bf16x8 *>(tlo + arow + 8 * (4 * ks + mh));
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], alo, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[ks], ahi, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], ahi, d, 0, 0, 0);
+  for (int k = 0; k < C::TPW; ++k) d[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    bf16x8 ahi[C::TPW], alo[C::TPW];
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k) {
+      const int arow = ((tt0 + k * C::TSTEP) * 16 + mi) * C::PB + 8 * (4 * ks + mh);
+      ahi[k] = *reinterpret_cast<const bf16x8 *>(thi + arow);
+      alo[k] = *reinterpret_cast<const bf16x8 *>(tlo + arow);
+    }
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k)
+      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], alo[k], d[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k)
+      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[ks], ahi[k], d[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k)
+      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], ahi[k], d[k], 0, 0, 0);
   }
-  return d;
+}
+
+// The same with W streamed: img = fragment-ordered image of k_split_w (hi at 0, lo at F*F bf16),
+// fragment (j, ks) of lane l at ((j KS + ks) 64 + l) x 16 bytes -- one contiguous KB per wave load.
+template <int F>
+__device__ inline void tiles_mma_stream(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh,
+                                        const bf16x8 *__restrict__ img, int j, int lane,
+                                        f32x4 (&d)[MCfg<F>::TPW]) {
+  using C = MCfg<F>;
+  const bf16x8 *ghi = img + (j * C::KS) * 64 + lane;
+  const bf16x8 *glo = ghi + F * F / 8;
+#pragma unroll
+  for (int k = 0; k < C::TPW; ++k) d[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 whi = ghi[0], wlo = glo[0];
+  // a rolled loop: unrolled, hipcc hoists all 2 KS fragment loads (128 VGPRs at F = 256) and spills
+#pragma unroll 1
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int kn = ks + 1 < C::KS ? ks + 1 : ks;           // unconditional load, one k-step ahead
+    const bf16x8 nhi = ghi[kn * 64], nlo = glo[kn * 64];
+    bf16x8 ahi[C::TPW], alo[C::TPW];
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k) {
+      const int arow = ((tt0 + k * C::TSTEP) * 16 + mi) * C::PB + 8 * (4 * ks + mh);
+      ahi[k] = *reinterpret_cast<const bf16x8 *>(thi + arow);
+      alo[k] = *reinterpret_cast<const bf16x8 *>(tlo + arow);
+    }
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k)
+      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[k], d[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k)
+      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[k], d[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < C::TPW; ++k)
+      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[k], d[k], 0, 0, 0);
+    whi = nhi;
+    wlo = nlo;
+  }
+}
+
+// W [F,F] fp32 -> hi / lo bf16 images in fragment order (see tiles_mma_stream); one wave per (j, ks)
+template <int F>
+__global__ __launch_bounds__(64) void k_split_w(const float *__restrict__ W, bf16x8 *__restrict__ img) {
+  constexpr int KS = F / 32;
+  const int lane = threadIdx.x, mi = lane & 15, mh = lane >> 4;
+  const int j = blockIdx.x / KS, ks = blockIdx.x % KS;
+  const float *wp = W + (int64_t)(j * 16 + mi) * F + 8 * (4 * ks + mh);
+  bf16x4 h0, l0, h1, l1;
+  split4(*reinterpret_cast<const float4_t *>(wp), h0, l0);
+  split4(*reinterpret_cast<const float4_t *>(wp + 4), h1, l1);
+  img[blockIdx.x * 64 + lane] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+  img[F * F / 8 + blockIdx.x * 64 + lane] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 }
 
 // SiLU on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each): x / (1 + 2^(-x log2 e))
@@ -115,7 +191,7 @@ struct Pass {
 };
 
 template <int F, int M1, int M2, bool SEG>
-__global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
+__global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     const float *__restrict__ A, const float *__restrict__ W1, const float *__restrict__ G1,
     const int32_t *__restrict__ idx1, const float *__restrict__ G2,
     const int32_t *__restrict__ idx2, const float *__restrict__ b1, const float *__restrict__ W2,
@@ -123,19 +199,24 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
     int32_t R, int act, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ tile_row, int32_t n_tiles, float *__restrict__ agg, int mean) {
   using C = MCfg<F>;
-  constexpr int NA = kRows * C::Q / (C::NWB * 64);         // 16-B pieces of A per thread and pass
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
-  __bf16 *thi = reinterpret_cast<__bf16 *>(lds_raw);
+  __bf16 *thi = reinterpret_cast<__bf16 *>(lds_raw);                    // A tile, hi / lo
   __bf16 *tlo = thi + kRows * C::PB;
-  float *ytile = reinterpret_cast<float *>(lds_raw);       // aliases the hi/lo tiles (phase 4 only)
+  float *ytile = reinterpret_cast<float *>(lds_raw);                     // aliases the A tile (phase 4)
+  __bf16 *hhi = reinterpret_cast<__bf16 *>(lds_raw + C::a_bytes);        // hidden tile, hi / lo
+  __bf16 *hlo = hhi + kRows * C::PB;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int mi = lane & 15, mh = lane >> 4;
   const int j = wave % C::NJ, tt0 = wave / C::NJ;
   const int c4 = j * 16 + 4 * mh;                          // this lane's 4 output columns
 
-  bf16x8 w1hi[C::KS], w1lo[C::KS], w2hi[C::KS], w2lo[C::KS];
-  load_w<F>(W1, j, mi, mh, w1hi, w1lo);
-  load_w<F>(W2, j, mi, mh, w2hi, w2lo);
+  // resident: this wave's hi/lo fragments of both matrices; streamed: W1 / W2 point at the images
+  constexpr int KR = C::STREAM ? 1 : C::KS;
+  bf16x8 w1hi[KR], w1lo[KR], w2hi[KR], w2lo[KR];
+  if constexpr (!C::STREAM) {
+    load_w<F>(W1, j, mi, mh, w1hi, w1lo);
+    load_w<F>(W2, j, mi, mh, w2hi, w2lo);
+  }
   float4_t b1v = {0.f, 0.f, 0.f, 0.f}, b2v = {0.f, 0.f, 0.f, 0.f};
   if (b1) b1v = *reinterpret_cast<const float4_t *>(b1 + c4);
   if (b2) b2v = *reinterpret_cast<const float4_t *>(b2 + c4);
@@ -171,25 +252,20 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
     rr = rr < last ? rr : last;
     return rr < 0 ? 0 : rr;
   };
-  float4_t areg[NA];
+  // A is read in the OUTPUT layout (this lane: rows (tt0 + k TSTEP) 16 + mi, columns c4 .. c4+3), so
+  // the residual of out = A + y is already in this lane's registers
+  float4_t areg[C::TPW];
   int32_t i1[C::TPW], i2[C::TPW];
   auto prefetch = [&](const Pass &p) {                     // A rows and gather indices of pass p
-    const char *ab = reinterpret_cast<const char *>(A + (int64_t)p.w0 * F);
-    const int32_t room = (p.e1 < R ? p.e1 : R) - 1 - p.w0;  // last valid local row (>= 0)
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      const int i = t + a * C::NWB * 64;
-      int row = i / C::Q;
-      row = row < room ? row : (room < 0 ? 0 : room);
-      areg[a] = *reinterpret_cast<const float4_t *>(ab + (uint32_t)(row * F * 4 + (i % C::Q) * 16));
-    }
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int32_t rr = clamp_row(p, (tt0 + k * C::TSTEP) * 16 + mi);
+      areg[k] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + c4);
       i1[k] = M1 == kIdx ? idx1[rr] : rr;
       i2[k] = M2 == kIdx ? idx2[rr] : rr;
     }
   };
+  const bool res_is_a = res == A;
 
   Pass cur, nxt;
   span(tile0, cur);
@@ -220,16 +296,17 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
       seg_e = rowptr[r < cur.r1 ? r + 1 : cur.r1];
     }
     // ---- phase 1: prefetched A rows -> hi/lo tiles -----------------------------------------------
+    float4_t rv[C::TPW];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      const int i = t + a * C::NWB * 64;
-      const int row = i / C::Q, q = i % C::Q;
-      float4_t v = areg[a];
+    for (int k = 0; k < C::TPW; ++k) {
+      const int row = (tt0 + k * C::TSTEP) * 16 + mi;
+      float4_t v = areg[k];
       if (row >= n) v = float4_t{0.f, 0.f, 0.f, 0.f};
+      rv[k] = v;
       bf16x4 h4, l4;
       split4(v, h4, l4);
-      *reinterpret_cast<bf16x4 *>(thi + row * C::PB + 4 * q) = h4;
-      *reinterpret_cast<bf16x4 *>(tlo + row * C::PB + 4 * q) = l4;
+      *reinterpret_cast<bf16x4 *>(thi + row * C::PB + c4) = h4;
+      *reinterpret_cast<bf16x4 *>(tlo + row * C::PB + c4) = l4;
     }
     // ---- the pass after this one: its rows and indices travel while this one computes -------------
     Pass fol = cur;
@@ -244,26 +321,25 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
     prefetch(fol);
     __syncthreads();
     // ---- phase 2: first contraction, activation --------------------------------------------------
-    float4_t h[C::TPW];
+    // (the hidden tile has its own LDS image: the previous pass's second contraction, which read it,
+    //  lies before the barrier above for every wave)
+    f32x4 d[C::TPW];
+    if constexpr (C::STREAM)
+      tiles_mma_stream<F>(thi, tlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W1), j, lane, d);
+    else
+      tiles_mma<F>(thi, tlo, tt0, mi, mh, w1hi, w1lo, d);
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
-      const f32x4 d = tile_mma<F>(thi, tlo, row * C::PB, mh, w1hi, w1lo);
-      h[k] = activate(float4_t{d[0], d[1], d[2], d[3]} + add[k], act);
-    }
-    __syncthreads();                                       // every wave has read the A tiles
-#pragma unroll
-    for (int k = 0; k < C::TPW; ++k) {
-      const int row = (tt0 + k * C::TSTEP) * 16 + mi;
+      const float4_t hk = activate(float4_t{d[k][0], d[k][1], d[k][2], d[k][3]} + add[k], act);
       bf16x4 h4, l4;
-      split4(h[k], h4, l4);
-      *reinterpret_cast<bf16x4 *>(thi + row * C::PB + c4) = h4;
-      *reinterpret_cast<bf16x4 *>(tlo + row * C::PB + c4) = l4;
+      split4(hk, h4, l4);
+      *reinterpret_cast<bf16x4 *>(hhi + row * C::PB + c4) = h4;
+      *reinterpret_cast<bf16x4 *>(hlo + row * C::PB + c4) = l4;
     }
-    // residual rows: requested before the second contraction, used after it
-    float4_t rv[C::TPW];
+    // residual rows other than A: requested before the second contraction, used after it
     const int64_t pass_off = (int64_t)cur.w0 * F;
-    if (res) {
+    if (res && !res_is_a) {
 #pragma unroll
       for (int k = 0; k < C::TPW; ++k) {
         int row = (tt0 + k * C::TSTEP) * 16 + mi;
@@ -275,11 +351,14 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
     __syncthreads();
     // ---- phase 3: second contraction, residual, store ---------------------------------------------
     float4_t y[C::TPW];
+    if constexpr (C::STREAM)
+      tiles_mma_stream<F>(hhi, hlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W2), j, lane, d);
+    else
+      tiles_mma<F>(hhi, hlo, tt0, mi, mh, w2hi, w2lo, d);
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
-      const f32x4 d = tile_mma<F>(thi, tlo, row * C::PB, mh, w2hi, w2lo);
-      y[k] = float4_t{d[0], d[1], d[2], d[3]} + b2v;
+      y[k] = float4_t{d[k][0], d[k][1], d[k][2], d[k][3]} + b2v;
       if (out && row < n) {
         float4_t o = y[k];
         if (res) o += rv[k];
@@ -289,7 +368,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
     }
     // ---- phase 4: sum the messages of each target row, in stored order ----------------------------
     if constexpr (SEG) {
-      __syncthreads();                                     // hi/lo tiles are dead: reuse as y tile
+      // the A tile is dead (every wave is past the barrier that followed its first contraction)
 #pragma unroll
       for (int k = 0; k < C::TPW; ++k) {
         const int row = (tt0 + k * C::TSTEP) * 16 + mi;
@@ -328,7 +407,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64) void k_mlp2(
       span(tn, nxt);
     }
     cur = fol;
-    __syncthreads();                                       // LDS is free for the next pass
+    if constexpr (SEG) __syncthreads();                    // the y tile aliases the next pass's A tile
   }
 }
 
@@ -355,9 +434,17 @@ template <int F, int M1, int M2>
 int launch(const float *A, const float *W1, const float *G1, const int32_t *idx1, const float *G2,
            const int32_t *idx2, const float *b1, const float *W2, const float *b2, const float *res,
            float *out, int64_t R, int act, const int32_t *rowptr, const int32_t *tile_row,
-           int64_t n_tiles, float *agg, int mean, hipStream_t st) {
+           int64_t n_tiles, float *agg, int mean, void *workspace, hipStream_t st) {
   using C = MCfg<F>;
   const bool seg = agg != nullptr;
+  if constexpr (C::STREAM) {           // pre-split both matrices into fragment-ordered bf16 images
+    bf16x8 *img1 = reinterpret_cast<bf16x8 *>(workspace), *img2 = img1 + 2 * F * F / 8;
+    k_split_w<F><<<C::NJ * C::KS, 64, 0, st>>>(W1, img1);
+    k_split_w<F><<<C::NJ * C::KS, 64, 0, st>>>(W2, img2);
+    GWEN_LAUNCH_CHECK();
+    W1 = reinterpret_cast<const float *>(img1);
+    W2 = reinterpret_cast<const float *>(img2);
+  }
   const int64_t tiles = seg ? n_tiles : (R + kRows - 1) / kRows;
   // W1 and W2 (2 x 16 F^2 bytes per block) are fetched once per block: one resident set of blocks
   // walks the tiles, each prefetching its next pass while it computes the current one
@@ -387,11 +474,11 @@ int launch_mode(int m1, int m2, const float *A, const float *W1, const float *G1
                 const float *G2, const int32_t *idx2, const float *b1, const float *W2,
                 const float *b2, const float *res, float *out, int64_t R, int act,
                 const int32_t *rowptr, const int32_t *tile_row, int64_t n_tiles, float *agg, int mean,
-                hipStream_t st) {
+                void *workspace, hipStream_t st) {
 #define GWEN_MODE(A1, A2)                                                                        \
   if (m1 == A1 && m2 == A2)                                                                      \
     return launch<F, A1, A2>(A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr,    \
-                             tile_row, n_tiles, agg, mean, st)
+                             tile_row, n_tiles, agg, mean, workspace, st)
   GWEN_MODE(kNone, kNone); GWEN_MODE(kSelf, kNone); GWEN_MODE(kIdx, kNone); GWEN_MODE(kIdx, kIdx);
 #undef GWEN_MODE
   return GWEN_EINVAL;
@@ -399,7 +486,14 @@ int launch_mode(int m1, int m2, const float *A, const float *W1, const float *G1
 
 }  // namespace
 
-extern "C" int gwen_mlp2_supported(int64_t F) { return F == 32 || F == 64 || F == 128 ? 1 : 0; }
+extern "C" int gwen_mlp2_supported(int64_t F) {
+  return F == 32 || F == 64 || F == 128 || F == 256 ? 1 : 0;
+}
+
+extern "C" int64_t gwen_mlp2_workspace_bytes(int64_t F) {
+  if (!gwen_mlp2_supported(F)) return GWEN_EINVAL;
+  return F > 128 ? 2 * 2 * F * F * 2 : 0;      // two matrices x (hi, lo) x bf16
+}
 
 extern "C" int64_t gwen_edge_tiles_count(int64_t E, int64_t T) {
   if (E < 0 || T < 1) return GWEN_EINVAL;
@@ -425,7 +519,8 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
                              const float *b1, const float *W2, const float *b2, const float *res,
                              float *out, int64_t R, int64_t F, int act, const int32_t *rowptr,
                              const int32_t *tile_row, int64_t n_tiles, float *agg, int64_t N_agg,
-                             int mean, gwen_stream_t stream_) {
+                             int mean, void *workspace, size_t workspace_bytes,
+                             gwen_stream_t stream_) {
   if (R < 0 || N_agg < 0 || n_tiles < 0 || G1_rows < 0 || G2_rows < 0) return GWEN_EINVAL;
   if (!gwen_mlp2_supported(F)) return GWEN_EINVAL;
   if (act != GWEN_ACT_NONE && act != GWEN_ACT_RELU && act != GWEN_ACT_SILU) return GWEN_EINVAL;
@@ -444,14 +539,16 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
   if ((G1 && G1_rows * F * 4 >= (int64_t(1) << 32)) || (G2 && G2_rows * F * 4 >= (int64_t(1) << 32)))
     return GWEN_ERANGE;              // 32-bit byte offsets into the tables
   if (out && (out == G1 || out == G2)) return GWEN_EINVAL;      // out may alias A / res row for row
-  const void *al[] = {A, W1, G1, G2, b1, W2, b2, res, out, agg};
+  const int64_t need = gwen_mlp2_workspace_bytes(F);
+  if (need > 0 && (!workspace || (int64_t)workspace_bytes < need)) return GWEN_ENOSPACE;
+  const void *al[] = {A, W1, G1, G2, b1, W2, b2, res, out, agg, need > 0 ? workspace : nullptr};
   for (const void *p : al)
     if (p && !gwen_aligned(p, 16)) return GWEN_EINVAL;
 #define GWEN_M(FF)                                                                                \
   if (F == FF)                                                                                    \
     return launch_mode<FF>(m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, \
-                           tile_row, n_tiles, agg, mean, st)
-  GWEN_M(32); GWEN_M(64); GWEN_M(128);
+                           tile_row, n_tiles, agg, mean, workspace, st)
+  GWEN_M(32); GWEN_M(64); GWEN_M(128); GWEN_M(256);
 #undef GWEN_M
   return GWEN_EINVAL;
 }

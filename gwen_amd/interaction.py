@@ -90,7 +90,7 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
     """K6 (gwen_mlp2_f32): returns (out, agg); ``agg`` only with ``graph`` (rows = its stored edges)."""
     f = a.size(-1)
     if a.dim() != 2 or not mlp2_supported(f):
-        raise ValueError(f"K6 needs [rows, F] with F in (32, 64, 128); got {tuple(a.shape)}")
+        raise ValueError(f"K6 needs [rows, F] with F in (32, 64, 128, 256); got {tuple(a.shape)}")
     if tuple(w1.shape) != (f, f) or tuple(w2.shape) != (f, f):
         raise ValueError("W1 and W2 must be [F, F]")
     ts = {"a": a, "w1": w1, "w2": w2, "b1": b1, "b2": b2, "g1": g1, "g2": g2, "res": res}
@@ -114,6 +114,8 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
         if graph.num_edges != rows:
             raise ValueError("A must hold one row per stored edge of the graph")
         agg = torch.empty(graph.num_dst, f, dtype=torch.float32, device=dev)
+    nws = int(_lib.lib().gwen_mlp2_workspace_bytes(f))
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws > 0 else None
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_mlp2_f32(
             _ptr(a), _ptr(w1), _ptr(g1), _ptr(idx1), 0 if g1 is None else g1.size(0),
@@ -121,7 +123,7 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
             _ptr(res), _ptr(out), rows, f, _ACT[act],
             _ptr(graph.rowptr) if graph else None, _ptr(graph.tile_row) if graph else None,
             graph.n_tiles if graph else 0, _ptr(agg), graph.num_dst if graph else 0, int(mean),
-            _stream(dev))
+            _ptr(ws), nws, _stream(dev))
     _lib.check(rc, "gwen_mlp2_f32")
     return out, agg
 

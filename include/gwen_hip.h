@@ -244,6 +244,8 @@ int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t c
  *   rowptr[N_agg] == R) and tile_row [n_tiles+1] comes from gwen_edge_tiles; every target row is
  *   summed by one block in stored order (no atomics; rows without entries get 0).
  *   The contractions use the 3xbf16 split (see gwen_gcn_layer_f32, exact = 0).
+ *   workspace: gwen_mlp2_workspace_bytes(F) bytes, 16-byte aligned (GWEN_ENOSPACE if smaller); only
+ *   F = 256 needs one -- its weights do not fit the register file and are streamed as bf16 images.
  *
  * gwen_edge_tiles: row-aligned tiling of a CSR's entries.  tile c owns the target rows whose first
  *   entry lies in [cT, (c+1)T); n_tiles = gwen_edge_tiles_count(E, T) = max(1, ceil(E/T)); T <= 64
@@ -253,7 +255,8 @@ int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t c
 #define GWEN_ACT_NONE 0
 #define GWEN_ACT_RELU 1
 #define GWEN_ACT_SILU 2
-int gwen_mlp2_supported(int64_t F);
+int gwen_mlp2_supported(int64_t F);          /* F in {32, 64, 128, 256} */
+int64_t gwen_mlp2_workspace_bytes(int64_t F); /* F = 256: room for the pre-split weight images; else 0 */
 int64_t gwen_edge_tiles_count(int64_t E, int64_t T);
 int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int64_t T, int32_t *tile_row,
                     int32_t *dst, gwen_stream_t stream);
@@ -261,7 +264,8 @@ int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_
                   int64_t G1_rows, const float *G2, const int32_t *idx2, int64_t G2_rows,
                   const float *b1, const float *W2, const float *b2, const float *res, float *out,
                   int64_t R, int64_t F, int act, const int32_t *rowptr, const int32_t *tile_row,
-                  int64_t n_tiles, float *agg, int64_t N_agg, int mean, gwen_stream_t stream);
+                  int64_t n_tiles, float *agg, int64_t N_agg, int mean, void *workspace,
+                  size_t workspace_bytes, gwen_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ def test_edge_tiles_are_row_aligned(ga, name):
     assert torch.equal(g.unsort_edges(g.sort_edges(x.to(DEV))).cpu(), x)
 
 
-@pytest.mark.parametrize("F", [32, 64, 128])
+@pytest.mark.parametrize("F", [32, 64, 128, 256])
 @pytest.mark.parametrize("rows", [1, 63, 64, 65, 1000])
 @pytest.mark.parametrize("act", ["none", "relu", "silu"])
 def test_row_mlp_vs_oracle(ga, F, rows, act):
@@ -95,7 +95,7 @@ def _params(F, seed):
 
 
 @pytest.mark.parametrize("name", ["mesh", "g2m", "m2g", "K125", "multi", "sparse", "star", "empty", "one_edge"])
-@pytest.mark.parametrize("F,act,aggr", [(64, "silu", "sum"), (32, "relu", "mean"), (128, "silu", "sum")])
+@pytest.mark.parametrize("F,act,aggr", [(64, "silu", "sum"), (32, "relu", "mean"), (128, "silu", "sum"), (256, "silu", "mean")])
 def test_interaction_block_vs_oracle(ga, name, F, act, aggr):
     from gwen_amd.interaction import InteractionNet, interaction_graph
     from oracle import interaction_oracle as IO
