@@ -1,0 +1,109 @@
+"""Encode-process-decode forecaster on InteractionNet blocks (BASELINE config c5).
+
+BUILD-DEFINED, PARITY UNPINNED -- the reference has neither grid/mesh graphs nor edge MLPs nor a
+rollout (its model is six GCNConv calls, /root/reference/src/gwen/models_gnn.py:
+135-157,:189-212).  BASELINE.json's north_star names "the InteractionNet/GraphConv edge-MLP +
+scatter-add node-aggregation block that propagates atmospheric state over the grid->mesh->grid graphs
+each rollout step"; this module is that loop, with semantics of this build's own choosing (restated on
+the CPU in oracle/interaction_oracle.py):
+
+    vg  = grid_x  Wg^T + bg                 vm = mesh_pos Wm^T + bm              (embedders, K3)
+    e_* = edge_feat_* We_*^T + be_*         edge_feat = [length, dx, dy, dz] of the edge
+    vm      = Encoder(vg, vm, e_g2m)        InteractionNet, grid -> mesh   (gwen_amd/interaction.py, K6)
+    vm, e_m = Processor_k(vm, vm, e_m)      InteractionNet, mesh -> mesh,  k = 1..steps
+    vg      = Decoder(vm, vg, e_m2g)        InteractionNet, mesh -> grid
+    grid_y  = grid_x + vg Wo^T + bo                                          (residual read-out, K3)
+
+The grid is the set of triangle centres of the geodesic mesh; every cell is linked with its three
+corner vertices (gwen_amd/g2m.py).  Static embeddings (vm, e_*) depend on the weights only and are
+computed once per ``forward`` / ``rollout`` call.  Inference only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .g2m import grid_mesh_edges
+from .interaction import EdgeGraph, InteractionNet, interaction_graph
+from .mesh import Mesh
+
+
+def edge_features(pos_src: np.ndarray, pos_dst: np.ndarray, edge_index: np.ndarray) -> np.ndarray:
+    """[E, 4] float32: chord length and displacement (target - source) of every edge."""
+    d = pos_dst[edge_index[1]] - pos_src[edge_index[0]]
+    return np.concatenate([np.linalg.norm(d, axis=1, keepdims=True), d], axis=1).astype(np.float32)
+
+
+@dataclass
+class ForecastGraphs:
+    g2m: EdgeGraph
+    mesh: EdgeGraph
+    m2g: EdgeGraph
+    mesh_pos: Tensor        # [Nm, 3]
+    f_g2m: Tensor           # [E, 4] each, in the STORED edge order of its graph
+    f_mesh: Tensor
+    f_m2g: Tensor
+
+
+class InteractionForecaster(nn.Module):
+    def __init__(self, grid_channels: int, hidden: int, steps: int = 4, activation: str = "silu",
+                 aggr: str = "sum"):
+        super().__init__()
+        self.grid_channels, self.hidden, self.steps = grid_channels, hidden, steps
+        self.grid_embed = nn.Linear(grid_channels, hidden)
+        self.mesh_embed = nn.Linear(3, hidden)
+        self.g2m_edge_embed = nn.Linear(4, hidden)
+        self.mesh_edge_embed = nn.Linear(4, hidden)
+        self.m2g_edge_embed = nn.Linear(4, hidden)
+        self.encoder = InteractionNet(hidden, activation, aggr)
+        self.processor = nn.ModuleList([InteractionNet(hidden, activation, aggr) for _ in range(steps)])
+        self.decoder = InteractionNet(hidden, activation, aggr)
+        self.readout = nn.Linear(hidden, grid_channels)
+
+    @staticmethod
+    def prepare(mesh: Mesh, device) -> ForecastGraphs:
+        g2m, m2g = grid_mesh_edges(mesh)
+        n_mesh, n_grid = mesh.num_nodes, mesh.faces.shape[0]
+        cell = mesh.pos[mesh.faces].mean(axis=1)
+        cell /= np.linalg.norm(cell, axis=1, keepdims=True)
+        gs = (interaction_graph(torch.from_numpy(g2m).to(device), n_grid, n_mesh),
+              interaction_graph(torch.from_numpy(mesh.edge_index).to(device), n_mesh, n_mesh),
+              interaction_graph(torch.from_numpy(m2g).to(device), n_mesh, n_grid))
+        feats = (edge_features(cell, mesh.pos, g2m), edge_features(mesh.pos, mesh.pos, mesh.edge_index),
+                 edge_features(mesh.pos, cell, m2g))
+        fs = [g.sort_edges(torch.from_numpy(f).to(device)) for g, f in zip(gs, feats)]
+        return ForecastGraphs(*gs, torch.from_numpy(mesh.pos.astype(np.float32)).to(device), *fs)
+
+    def _static(self, graphs: ForecastGraphs):
+        lin = lambda x, m: ops.linear(x, m.weight, m.bias, exact=False)      # noqa: E731
+        return (lin(graphs.mesh_pos, self.mesh_embed), lin(graphs.f_g2m, self.g2m_edge_embed),
+                lin(graphs.f_mesh, self.mesh_edge_embed), lin(graphs.f_m2g, self.m2g_edge_embed))
+
+    def _step(self, grid_x: Tensor, graphs: ForecastGraphs, static) -> Tensor:
+        vm, e_g2m, e_m, e_m2g = static
+        vg = ops.linear(grid_x, self.grid_embed.weight, self.grid_embed.bias, exact=False)
+        vm, _ = self.encoder(vg, vm, e_g2m, graphs.g2m, update_edges=False)
+        for net in self.processor:
+            vm, e_m = net(vm, vm, e_m, graphs.mesh)
+        vg, _ = self.decoder(vm, vg, e_m2g, graphs.m2g, update_edges=False)
+        return grid_x + ops.linear(vg, self.readout.weight, self.readout.bias, exact=False)
+
+    def forward(self, grid_x: Tensor, graphs: ForecastGraphs) -> Tensor:
+        if torch.is_grad_enabled() and (grid_x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("InteractionForecaster is inference-only: call it under torch.no_grad()")
+        return self._step(grid_x, graphs, self._static(graphs))
+
+    def rollout(self, grid_x: Tensor, graphs: ForecastGraphs, n_steps: int) -> List[Tensor]:
+        """Autoregressive: state_{t+1} = forward(state_t); returns the n_steps states."""
+        states, cur = [], grid_x
+        with torch.no_grad():
+            static = self._static(graphs)
+            for _ in range(n_steps):
+                cur = self._step(cur, graphs, static)
+                states.append(cur)
+        return states

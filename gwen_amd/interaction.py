@@ -144,6 +144,23 @@ class InteractionNet(nn.Module):
         self.channels, self.activation, self.aggr = channels, activation, aggr
         self.edge_mlp = _mlp(3 * channels, channels, activation)
         self.node_mlp = _mlp(2 * channels, channels, activation)
+        self._blocks = None          # contiguous [F,F] blocks of the two first layers + their versions
+
+    def _weight_blocks(self):
+        """edge_mlp.0.weight = [We | Ws | Wd], node_mlp.0.weight = [Wx | Wa] as contiguous [F,F] blocks,
+        re-cut only when a parameter changed (in-place version counter) or moved."""
+        w1, w3, f = self.edge_mlp[0].weight, self.node_mlp[0].weight, self.channels
+        key = (w1._version, w3._version, w1.data_ptr(), w3.data_ptr())
+        if self._blocks is None or self._blocks[0] != key:
+            with torch.no_grad():
+                cut = tuple(w[:, i * f:(i + 1) * f].contiguous() for w, n in ((w1, 3), (w3, 2)) for i in range(n))
+            self._blocks = (key, cut)
+        return self._blocks[1]
+
+    def __getstate__(self):          # the cache is derived data: keep modules picklable and small
+        state = self.__dict__.copy()
+        state["_blocks"] = None
+        return state
 
     def forward(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph,
                 update_edges: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
@@ -153,14 +170,13 @@ class InteractionNet(nn.Module):
         if x_src.shape != (graph.num_src, f) or x_dst.shape != (graph.num_dst, f) or \
                 e.shape != (graph.num_edges, f):
             raise ValueError("x_src / x_dst / e do not match the graph and the channel count")
-        w1, b1 = self.edge_mlp[0].weight, self.edge_mlp[0].bias
-        w3, b3 = self.node_mlp[0].weight, self.node_mlp[0].bias
-        ps = ops.linear(x_src, w1[:, f:2 * f], None, exact=False)
-        pd = ops.linear(x_dst, w1[:, 2 * f:], b1, exact=False)
-        e_new, agg = mlp2(e, w1[:, :f], self.edge_mlp[2].weight, self.edge_mlp[2].bias,
+        we, ws, wd, wx, wa = self._weight_blocks()
+        ps = ops.linear(x_src, ws, None, exact=False)
+        pd = ops.linear(x_dst, wd, self.edge_mlp[0].bias, exact=False)
+        e_new, agg = mlp2(e, we, self.edge_mlp[2].weight, self.edge_mlp[2].bias,
                           g1=ps, idx1=graph.src, g2=pd, idx2=graph.dst, res=e, act=self.activation,
                           graph=graph, mean=self.aggr == "mean", want_out=update_edges)
-        q = ops.linear(x_dst, w3[:, :f], b3, exact=False)
-        x_new, _ = mlp2(agg, w3[:, f:], self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
+        q = ops.linear(x_dst, wx, self.node_mlp[0].bias, exact=False)
+        x_new, _ = mlp2(agg, wa, self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
                         res=x_dst, act=self.activation)
         return x_new, e_new

@@ -50,3 +50,22 @@ def interaction(x_src: Tensor, x_dst: Tensor, e: Tensor, edge_index: Tensor, par
     x_new = x_dst + mlp2(torch.cat([x_dst, agg], dim=1), p["node_mlp.0.weight"], p["node_mlp.0.bias"],
                          p["node_mlp.2.weight"], p["node_mlp.2.bias"], act)
     return x_new, e + m
+
+
+def _sub(sd: dict, prefix: str) -> dict:
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def forecaster_step(sd: dict, grid_x: Tensor, mesh_pos: Tensor, g2m: Tensor, mesh_ei: Tensor, m2g: Tensor,
+                    f_g2m: Tensor, f_mesh: Tensor, f_m2g: Tensor, steps: int, act: str = "silu",
+                    aggr: str = "sum") -> Tensor:
+    """One step of gwen_amd/forecaster.py's InteractionForecaster; edge lists and edge features in the
+    SAME (caller's) order.  ``sd`` = its state_dict."""
+    lin = lambda x, name: x @ sd[name + ".weight"].t() + sd[name + ".bias"]      # noqa: E731
+    vg, vm = lin(grid_x, "grid_embed"), lin(mesh_pos, "mesh_embed")
+    e_g2m, e_m, e_m2g = lin(f_g2m, "g2m_edge_embed"), lin(f_mesh, "mesh_edge_embed"), lin(f_m2g, "m2g_edge_embed")
+    vm, _ = interaction(vg, vm, e_g2m, g2m, _sub(sd, "encoder."), act, aggr)
+    for k in range(steps):
+        vm, e_m = interaction(vm, vm, e_m, mesh_ei, _sub(sd, f"processor.{k}."), act, aggr)
+    vg, _ = interaction(vm, vg, e_m2g, m2g, _sub(sd, "decoder."), act, aggr)
+    return grid_x + lin(vg, "readout")

@@ -169,3 +169,38 @@ def test_rejects_misuse(ga):
         net(torch.randn(3, 64, device=DEV), torch.randn(3, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
     with torch.no_grad(), pytest.raises(ValueError):
         net(torch.randn(4, 64, device=DEV), torch.randn(3, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
+
+
+@pytest.mark.parametrize("C,H,steps,nsteps", [(8, 32, 1, 2), (16, 64, 2, 3), (5, 128, 1, 1)])
+def test_forecaster_and_rollout_vs_oracle(ga, C, H, steps, nsteps):
+    """grid -> mesh -> grid encode-process-decode on InteractionNet blocks, autoregressive rollout."""
+    from gwen_amd import g2m
+    from gwen_amd.forecaster import InteractionForecaster, edge_features
+    from oracle import interaction_oracle as IO
+    m = ga.geodesic_mesh(5)
+    torch.manual_seed(SEED)
+    model = InteractionForecaster(C, H, steps)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    a, b = g2m.grid_mesh_edges(m)
+    cell = m.pos[m.faces].mean(axis=1)
+    cell /= np.linalg.norm(cell, axis=1, keepdims=True)
+    f = [torch.from_numpy(x).double() for x in (edge_features(cell, m.pos, a), edge_features(m.pos, m.pos, m.edge_index),
+                                                 edge_features(m.pos, cell, b))]
+    sd = {k: v.double() for k, v in model.state_dict().items()}
+    x0 = torch.randn(m.faces.shape[0], C, generator=torch.Generator().manual_seed(SEED))
+    want, cur = [], x0.double()
+    for _ in range(nsteps):
+        cur = IO.forecaster_step(sd, cur, torch.from_numpy(m.pos.astype(np.float32)).double(), torch.from_numpy(a),
+                                 torch.from_numpy(m.edge_index), torch.from_numpy(b), *f, steps)
+        want.append(cur)
+    graphs = InteractionForecaster.prepare(m, DEV)
+    model = model.to(DEV)
+    got = model.rollout(x0.to(DEV), graphs, nsteps)
+    with torch.no_grad():
+        one = model(x0.to(DEV), graphs)
+    assert torch.equal(one, got[0])
+    for g_, w_ in zip(got, want):
+        assert rel_err(g_, w_) <= REL_TOL

@@ -27,11 +27,12 @@ def main():
     ap.add_argument("--nu", type=int, default=100)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--graph", default="mesh", choices=["mesh", "g2m", "m2g"])
+    ap.add_argument("--reorder", default="morton", choices=["none", "morton"])
     ap.add_argument("--act", default="silu", choices=["none", "relu", "silu"])
     args = ap.parse_args()
     dev = "cuda:0"
     F = args.channels
-    mesh = gwen_amd.geodesic_mesh(args.nu)
+    mesh = gwen_amd.geodesic_mesh(args.nu, reorder=None if args.reorder == 'none' else args.reorder)
     if args.graph == "mesh":
         ei, ns, nd = torch.from_numpy(mesh.edge_index), mesh.num_nodes, mesh.num_nodes
     else:
