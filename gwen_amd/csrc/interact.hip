@@ -37,11 +37,15 @@ template <int F>
 struct MCfg {
   static constexpr int NJ = F / 16;                              // 16-column output tiles
   static constexpr int NT = kRows / 16;
-  // every column tile is shared by TSTEP waves (each takes every TSTEP-th row tile): 8 or 16 light
-  // waves per block instead of 4 heavy ones -- four waves per SIMD fit the register file
+  // A wave owns NC column tiles.  With one tile every hi/lo operand pair read from LDS feeds three
+  // MFMAs, with two it feeds six: at 256 channels (16 column tiles, weights streamed anyway) two
+  // tiles per wave measured 10 % faster; at 64 the doubled fragments and tiles spill, at 128 it is a wash.
+  static constexpr int NC = F == 256 ? 2 : 1;
+  static constexpr int NJW = NJ / NC;                            // column groups
+  // every column group is shared by TSTEP waves (each takes every TSTEP-th 16-row tile)
   static constexpr int TSTEP = F == 32 ? 4 : (F == 64 ? 2 : 1);
-  static constexpr int NWB = NJ * TSTEP;                         // waves per block
-  static constexpr int MINW = F == 128 ? 2 : 4;                  // waves per SIMD to compile for
+  static constexpr int NWB = NJW * TSTEP;                        // waves per block: 8 at every width
+  static constexpr int MINW = F >= 128 ? 2 : 4;                  // waves per SIMD to compile for
   // F = 256: the two weight matrices as hi/lo fragments are 512 KB -- the whole register file of a
   // CU -- so they cannot stay resident: they are pre-split once per launch into fragment-ordered bf16
   // images (k_split_w) and every wave streams its slices from L2, one k-step ahead of the MFMAs
@@ -57,7 +61,7 @@ struct MCfg {
   static constexpr size_t lds_bytes = a_bytes + split_bytes;
   static constexpr int Q = F / 4;                                // 16-B pieces per row
   static constexpr int SLOTS = NWB * 64 / Q;                     // target rows reduced at a time
-  static_assert(NT % TSTEP == 0, "row tiles must divide over the waves");
+  static_assert(NT % TSTEP == 0 && NJ % NC == 0, "tiles must divide over the waves");
 };
 
 __device__ inline void split4(const float4_t v, bf16x4 &hi, bf16x4 &lo) {
@@ -69,11 +73,11 @@ __device__ inline void split4(const float4_t v, bf16x4 &hi, bf16x4 &lo) {
   }
 }
 
-// this wave's 16 output columns of W^T (W is [F,F] row-major [out,in]) as hi/lo A-operand fragments
+// column tile jt (16 output columns) of W^T (W is [F,F] row-major [out,in]) as hi/lo A-operand fragments
 template <int F>
-__device__ inline void load_w(const float *__restrict__ W, int j, int mi, int mh,
+__device__ inline void load_w(const float *__restrict__ W, int jt, int mi, int mh,
                               bf16x8 (&whi)[MCfg<F>::KS], bf16x8 (&wlo)[MCfg<F>::KS]) {
-  const float *wrow = W + (int64_t)(j * 16 + mi) * F;
+  const float *wrow = W + (int64_t)(jt * 16 + mi) * F;
 #pragma unroll
   for (int ks = 0; ks < MCfg<F>::KS; ++ks) {
     const float4_t a = *reinterpret_cast<const float4_t *>(wrow + 8 * (4 * ks + mh));
@@ -86,71 +90,103 @@ __device__ inline void load_w(const float *__restrict__ W, int j, int mi, int mh
   }
 }
 
-// TPW row tiles at once: the three products of a k-step go to TPW independent accumulators before
-// the next product touches the same one, so no MFMA waits for the one issued just before it
+// One k-step of TPW row tiles x NC column tiles: the operand pairs are read once, the products of
+// one kind go to all TPW * NC independent accumulators before the next kind touches them again.
 template <int F>
-__device__ inline void tiles_mma(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh,
-                                 const bf16x8 (&whi)[MCfg<F>::KS], const bf16x8 (&wlo)[MCfg<F>::KS],
-                                 f32x4 (&d)[MCfg<F>::TPW]) {
+__device__ inline void mma_step(const bf16x8 (&ahi)[MCfg<F>::TPW], const bf16x8 (&alo)[MCfg<F>::TPW],
+                                const bf16x8 (&whi)[MCfg<F>::NC], const bf16x8 (&wlo)[MCfg<F>::NC],
+                                f32x4 (&d)[MCfg<F>::TPW][MCfg<F>::NC]) {
   using C = MCfg<F>;
 #pragma unroll
-  for (int k = 0; k < C::TPW; ++k) d[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
-    bf16x8 ahi[C::TPW], alo[C::TPW];
-#pragma unroll
-    for (int k = 0; k < C::TPW; ++k) {
-      const int arow = ((tt0 + k * C::TSTEP) * 16 + mi) * C::PB + 8 * (4 * ks + mh);
-      ahi[k] = *reinterpret_cast<const bf16x8 *>(thi + arow);
-      alo[k] = *reinterpret_cast<const bf16x8 *>(tlo + arow);
-    }
+  for (int n = 0; n < C::NC; ++n)
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k)
-      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], alo[k], d[k], 0, 0, 0);
+      d[k][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[n], alo[k], d[k][n], 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < C::NC; ++n)
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k)
-      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[ks], ahi[k], d[k], 0, 0, 0);
+      d[k][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[n], ahi[k], d[k][n], 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < C::NC; ++n)
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k)
-      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], ahi[k], d[k], 0, 0, 0);
+      d[k][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[n], ahi[k], d[k][n], 0, 0, 0);
+}
+
+template <int F>
+__device__ inline void read_tiles(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh, int ks,
+                                  bf16x8 (&ahi)[MCfg<F>::TPW], bf16x8 (&alo)[MCfg<F>::TPW]) {
+  using C = MCfg<F>;
+#pragma unroll
+  for (int k = 0; k < C::TPW; ++k) {
+    const int arow = ((tt0 + k * C::TSTEP) * 16 + mi) * C::PB + 8 * (4 * ks + mh);
+    ahi[k] = *reinterpret_cast<const bf16x8 *>(thi + arow);
+    alo[k] = *reinterpret_cast<const bf16x8 *>(tlo + arow);
   }
 }
 
-// The same with W streamed: img = fragment-ordered image of k_split_w (hi at 0, lo at F*F bf16),
-// fragment (j, ks) of lane l at ((j KS + ks) 64 + l) x 16 bytes -- one contiguous KB per wave load.
+// weights resident in registers
+template <int F>
+__device__ inline void tiles_mma(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh,
+                                 const bf16x8 (&whi)[MCfg<F>::NC][MCfg<F>::KS],
+                                 const bf16x8 (&wlo)[MCfg<F>::NC][MCfg<F>::KS],
+                                 f32x4 (&d)[MCfg<F>::TPW][MCfg<F>::NC]) {
+  using C = MCfg<F>;
+#pragma unroll
+  for (int k = 0; k < C::TPW; ++k)
+#pragma unroll
+    for (int n = 0; n < C::NC; ++n) d[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    bf16x8 ahi[C::TPW], alo[C::TPW], wh[C::NC], wl[C::NC];
+    read_tiles<F>(thi, tlo, tt0, mi, mh, ks, ahi, alo);
+#pragma unroll
+    for (int n = 0; n < C::NC; ++n) {
+      wh[n] = whi[n][ks];
+      wl[n] = wlo[n][ks];
+    }
+    mma_step<F>(ahi, alo, wh, wl, d);
+  }
+}
+
+// weights streamed: img = fragment-ordered image of k_split_w (hi at 0, lo at F*F bf16), fragment
+// (jt, ks) of lane l at ((jt KS + ks) 64 + l) x 16 bytes -- one contiguous KB per wave load.
 template <int F>
 __device__ inline void tiles_mma_stream(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh,
-                                        const bf16x8 *__restrict__ img, int j, int lane,
-                                        f32x4 (&d)[MCfg<F>::TPW]) {
+                                        const bf16x8 *__restrict__ img, int jw, int lane,
+                                        f32x4 (&d)[MCfg<F>::TPW][MCfg<F>::NC]) {
   using C = MCfg<F>;
-  const bf16x8 *ghi = img + (j * C::KS) * 64 + lane;
+  const bf16x8 *ghi = img + (jw * C::NC * C::KS) * 64 + lane;
   const bf16x8 *glo = ghi + F * F / 8;
 #pragma unroll
-  for (int k = 0; k < C::TPW; ++k) d[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 whi = ghi[0], wlo = glo[0];
-  // a rolled loop: unrolled, hipcc hoists all 2 KS fragment loads (128 VGPRs at F = 256) and spills
+  for (int k = 0; k < C::TPW; ++k)
+#pragma unroll
+    for (int n = 0; n < C::NC; ++n) d[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 wh[C::NC], wl[C::NC];
+#pragma unroll
+  for (int n = 0; n < C::NC; ++n) {
+    wh[n] = ghi[n * C::KS * 64];
+    wl[n] = glo[n * C::KS * 64];
+  }
+  // a rolled loop: unrolled, hipcc hoists every fragment load of the contraction and spills
 #pragma unroll 1
   for (int ks = 0; ks < C::KS; ++ks) {
     const int kn = ks + 1 < C::KS ? ks + 1 : ks;           // unconditional load, one k-step ahead
-    const bf16x8 nhi = ghi[kn * 64], nlo = glo[kn * 64];
-    bf16x8 ahi[C::TPW], alo[C::TPW];
+    bf16x8 nh[C::NC], nl[C::NC];
 #pragma unroll
-    for (int k = 0; k < C::TPW; ++k) {
-      const int arow = ((tt0 + k * C::TSTEP) * 16 + mi) * C::PB + 8 * (4 * ks + mh);
-      ahi[k] = *reinterpret_cast<const bf16x8 *>(thi + arow);
-      alo[k] = *reinterpret_cast<const bf16x8 *>(tlo + arow);
+    for (int n = 0; n < C::NC; ++n) {
+      nh[n] = ghi[(n * C::KS + kn) * 64];
+      nl[n] = glo[(n * C::KS + kn) * 64];
     }
+    bf16x8 ahi[C::TPW], alo[C::TPW];
+    read_tiles<F>(thi, tlo, tt0, mi, mh, ks, ahi, alo);
+    mma_step<F>(ahi, alo, wh, wl, d);
 #pragma unroll
-    for (int k = 0; k < C::TPW; ++k)
-      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[k], d[k], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < C::TPW; ++k)
-      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[k], d[k], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < C::TPW; ++k)
-      d[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[k], d[k], 0, 0, 0);
-    whi = nhi;
-    wlo = nlo;
+    for (int n = 0; n < C::NC; ++n) {
+      wh[n] = nh[n];
+      wl[n] = nl[n];
+    }
   }
 }
 
@@ -207,19 +243,26 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
   __bf16 *hlo = hhi + kRows * C::PB;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int mi = lane & 15, mh = lane >> 4;
-  const int j = wave % C::NJ, tt0 = wave / C::NJ;
-  const int c4 = j * 16 + 4 * mh;                          // this lane's 4 output columns
+  const int jw = wave % C::NJW, tt0 = wave / C::NJW;
+  // this lane's output columns: 4 consecutive ones in each of the wave's NC column tiles
+  auto col = [&](int n) { return (jw * C::NC + n) * 16 + 4 * mh; };
 
   // resident: this wave's hi/lo fragments of both matrices; streamed: W1 / W2 point at the images
   constexpr int KR = C::STREAM ? 1 : C::KS;
-  bf16x8 w1hi[KR], w1lo[KR], w2hi[KR], w2lo[KR];
+  bf16x8 w1hi[C::NC][KR], w1lo[C::NC][KR], w2hi[C::NC][KR], w2lo[C::NC][KR];
   if constexpr (!C::STREAM) {
-    load_w<F>(W1, j, mi, mh, w1hi, w1lo);
-    load_w<F>(W2, j, mi, mh, w2hi, w2lo);
+#pragma unroll
+    for (int n = 0; n < C::NC; ++n) {
+      load_w<F>(W1, jw * C::NC + n, mi, mh, w1hi[n], w1lo[n]);
+      load_w<F>(W2, jw * C::NC + n, mi, mh, w2hi[n], w2lo[n]);
+    }
   }
-  float4_t b1v = {0.f, 0.f, 0.f, 0.f}, b2v = {0.f, 0.f, 0.f, 0.f};
-  if (b1) b1v = *reinterpret_cast<const float4_t *>(b1 + c4);
-  if (b2) b2v = *reinterpret_cast<const float4_t *>(b2 + c4);
+  float4_t b1v[C::NC], b2v[C::NC];
+#pragma unroll
+  for (int n = 0; n < C::NC; ++n) {
+    b1v[n] = b1 ? *reinterpret_cast<const float4_t *>(b1 + col(n)) : float4_t{0.f, 0.f, 0.f, 0.f};
+    b2v[n] = b2 ? *reinterpret_cast<const float4_t *>(b2 + col(n)) : float4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
   // tiles are dealt so that the blocks of one XCD (blockIdx % 8) walk ONE contiguous eighth of them:
   // neighbouring tiles gather neighbouring table rows, which then meet in that XCD's L2
@@ -252,15 +295,17 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     rr = rr < last ? rr : last;
     return rr < 0 ? 0 : rr;
   };
-  // A is read in the OUTPUT layout (this lane: rows (tt0 + k TSTEP) 16 + mi, columns c4 .. c4+3), so
+  // A is read in the OUTPUT layout (this lane: rows (tt0 + k TSTEP) 16 + mi, columns col(n) .. +3), so
   // the residual of out = A + y is already in this lane's registers
-  float4_t areg[C::TPW];
+  float4_t areg[C::TPW][C::NC];
   int32_t i1[C::TPW], i2[C::TPW];
   auto prefetch = [&](const Pass &p) {                     // A rows and gather indices of pass p
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int32_t rr = clamp_row(p, (tt0 + k * C::TSTEP) * 16 + mi);
-      areg[k] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + c4);
+#pragma unroll
+      for (int n = 0; n < C::NC; ++n)
+        areg[k][n] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + col(n));
       i1[k] = M1 == kIdx ? idx1[rr] : rr;
       i2[k] = M2 == kIdx ? idx2[rr] : rr;
     }
@@ -275,19 +320,21 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
   }
   prefetch(cur);
   for (;;) {
-    const int32_t n = cur.e1 - cur.w0;                     // valid rows of this pass (<= 0: none)
+    const int32_t n_rows = cur.e1 - cur.w0;                // valid rows of this pass (<= 0: none)
     // ---- the gathered addends of this lane's rows (indices came with the prefetch) ---------------
-    float4_t add[C::TPW];
+    float4_t add[C::TPW][C::NC];
 #pragma unroll
-    for (int k = 0; k < C::TPW; ++k) {
-      add[k] = b1v;
-      if constexpr (M1 != kNone)
-        add[k] += *reinterpret_cast<const float4_t *>(
-            reinterpret_cast<const char *>(G1) + ((uint32_t)i1[k] * (F * 4u) + c4 * 4u));
-      if constexpr (M2 != kNone)
-        add[k] += *reinterpret_cast<const float4_t *>(
-            reinterpret_cast<const char *>(G2) + ((uint32_t)i2[k] * (F * 4u) + c4 * 4u));
-    }
+    for (int k = 0; k < C::TPW; ++k)
+#pragma unroll
+      for (int n = 0; n < C::NC; ++n) {
+        add[k][n] = b1v[n];
+        if constexpr (M1 != kNone)
+          add[k][n] += *reinterpret_cast<const float4_t *>(
+              reinterpret_cast<const char *>(G1) + ((uint32_t)i1[k] * (F * 4u) + col(n) * 4u));
+        if constexpr (M2 != kNone)
+          add[k][n] += *reinterpret_cast<const float4_t *>(
+              reinterpret_cast<const char *>(G2) + ((uint32_t)i2[k] * (F * 4u) + col(n) * 4u));
+      }
     // phase 4's row bounds for this thread's first target row, requested early
     int32_t seg_s = 0, seg_e = 0;
     if constexpr (SEG) {
@@ -296,17 +343,20 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
       seg_e = rowptr[r < cur.r1 ? r + 1 : cur.r1];
     }
     // ---- phase 1: prefetched A rows -> hi/lo tiles -----------------------------------------------
-    float4_t rv[C::TPW];
+    float4_t rv[C::TPW][C::NC];
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
-      float4_t v = areg[k];
-      if (row >= n) v = float4_t{0.f, 0.f, 0.f, 0.f};
-      rv[k] = v;
-      bf16x4 h4, l4;
-      split4(v, h4, l4);
-      *reinterpret_cast<bf16x4 *>(thi + row * C::PB + c4) = h4;
-      *reinterpret_cast<bf16x4 *>(tlo + row * C::PB + c4) = l4;
+#pragma unroll
+      for (int n = 0; n < C::NC; ++n) {
+        float4_t v = areg[k][n];
+        if (row >= n_rows) v = float4_t{0.f, 0.f, 0.f, 0.f};
+        rv[k][n] = v;
+        bf16x4 h4, l4;
+        split4(v, h4, l4);
+        *reinterpret_cast<bf16x4 *>(thi + row * C::PB + col(n)) = h4;
+        *reinterpret_cast<bf16x4 *>(tlo + row * C::PB + col(n)) = l4;
+      }
     }
     // ---- the pass after this one: its rows and indices travel while this one computes -------------
     Pass fol = cur;
@@ -323,19 +373,23 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     // ---- phase 2: first contraction, activation --------------------------------------------------
     // (the hidden tile has its own LDS image: the previous pass's second contraction, which read it,
     //  lies before the barrier above for every wave)
-    f32x4 d[C::TPW];
+    f32x4 d[C::TPW][C::NC];
     if constexpr (C::STREAM)
-      tiles_mma_stream<F>(thi, tlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W1), j, lane, d);
+      tiles_mma_stream<F>(thi, tlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W1), jw, lane, d);
     else
       tiles_mma<F>(thi, tlo, tt0, mi, mh, w1hi, w1lo, d);
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
-      const float4_t hk = activate(float4_t{d[k][0], d[k][1], d[k][2], d[k][3]} + add[k], act);
-      bf16x4 h4, l4;
-      split4(hk, h4, l4);
-      *reinterpret_cast<bf16x4 *>(hhi + row * C::PB + c4) = h4;
-      *reinterpret_cast<bf16x4 *>(hlo + row * C::PB + c4) = l4;
+#pragma unroll
+      for (int n = 0; n < C::NC; ++n) {
+        const float4_t hk =
+            activate(float4_t{d[k][n][0], d[k][n][1], d[k][n][2], d[k][n][3]} + add[k][n], act);
+        bf16x4 h4, l4;
+        split4(hk, h4, l4);
+        *reinterpret_cast<bf16x4 *>(hhi + row * C::PB + col(n)) = h4;
+        *reinterpret_cast<bf16x4 *>(hlo + row * C::PB + col(n)) = l4;
+      }
     }
     // residual rows other than A: requested before the second contraction, used after it
     const int64_t pass_off = (int64_t)cur.w0 * F;
@@ -343,27 +397,32 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
 #pragma unroll
       for (int k = 0; k < C::TPW; ++k) {
         int row = (tt0 + k * C::TSTEP) * 16 + mi;
-        row = row < n ? row : (n > 0 ? n - 1 : 0);
-        rv[k] = *reinterpret_cast<const float4_t *>(
-            reinterpret_cast<const char *>(res + pass_off) + (uint32_t)(row * F * 4 + c4 * 4));
+        row = row < n_rows ? row : (n_rows > 0 ? n_rows - 1 : 0);
+#pragma unroll
+        for (int n = 0; n < C::NC; ++n)
+          rv[k][n] = *reinterpret_cast<const float4_t *>(
+              reinterpret_cast<const char *>(res + pass_off) + (uint32_t)(row * F * 4 + col(n) * 4));
       }
     }
     __syncthreads();
     // ---- phase 3: second contraction, residual, store ---------------------------------------------
-    float4_t y[C::TPW];
+    float4_t y[C::TPW][C::NC];
     if constexpr (C::STREAM)
-      tiles_mma_stream<F>(hhi, hlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W2), j, lane, d);
+      tiles_mma_stream<F>(hhi, hlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W2), jw, lane, d);
     else
       tiles_mma<F>(hhi, hlo, tt0, mi, mh, w2hi, w2lo, d);
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
-      y[k] = float4_t{d[k][0], d[k][1], d[k][2], d[k][3]} + b2v;
-      if (out && row < n) {
-        float4_t o = y[k];
-        if (res) o += rv[k];
-        *reinterpret_cast<float4_t *>(reinterpret_cast<char *>(out + pass_off) +
-                                      (uint32_t)(row * F * 4 + c4 * 4)) = o;
+#pragma unroll
+      for (int n = 0; n < C::NC; ++n) {
+        y[k][n] = float4_t{d[k][n][0], d[k][n][1], d[k][n][2], d[k][n][3]} + b2v[n];
+        if (out && row < n_rows) {
+          float4_t o = y[k][n];
+          if (res) o += rv[k][n];
+          *reinterpret_cast<float4_t *>(reinterpret_cast<char *>(out + pass_off) +
+                                        (uint32_t)(row * F * 4 + col(n) * 4)) = o;
+        }
       }
     }
     // ---- phase 4: sum the messages of each target row, in stored order ----------------------------
@@ -372,7 +431,9 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
 #pragma unroll
       for (int k = 0; k < C::TPW; ++k) {
         const int row = (tt0 + k * C::TSTEP) * 16 + mi;
-        *reinterpret_cast<float4_t *>(ytile + row * C::PY + c4) = y[k];
+#pragma unroll
+        for (int n = 0; n < C::NC; ++n)
+          *reinterpret_cast<float4_t *>(ytile + row * C::PY + col(n)) = y[k][n];
       }
       __syncthreads();
       const int q = t % C::Q;
