@@ -31,12 +31,15 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRows = 64;                 // rows per pass (4 MFMA row tiles)
+constexpr int kMaxRows = 64;              // most rows a pass takes (MCfg<F>::ROWS)
 
 template <int F>
 struct MCfg {
   static constexpr int NJ = F / 16;                              // 16-column output tiles
-  static constexpr int NT = kRows / 16;
+  // rows per pass.  (32 at 128 channels -- half the per-wave state, two blocks per CU -- measured
+  // slower: 357 vs 259 us, twice the passes and their fixed costs.)
+  static constexpr int ROWS = 64;
+  static constexpr int NT = ROWS / 16;
   // A wave owns NC column tiles.  With one tile every hi/lo operand pair read from LDS feeds three
   // MFMAs, with two it feeds six: at 256 channels (16 column tiles, weights streamed anyway) two
   // tiles per wave measured 10 % faster; at 64 the doubled fragments and tiles spill, at 128 it is a wash.
@@ -54,8 +57,8 @@ struct MCfg {
   static constexpr int KS = F / 32;                              // k-steps of v_mfma_f32_16x16x32_bf16
   static constexpr int PB = ((F / 2) % 16 == 8 ? F / 2 : F / 2 + 8) * 2;   // hi/lo tile pitch (bf16)
   static constexpr int PY = F + 4;                               // y tile pitch (floats)
-  static constexpr size_t split_bytes = (size_t)2 * kRows * PB * 2;
-  static constexpr size_t y_bytes = (size_t)kRows * PY * 4;
+  static constexpr size_t split_bytes = (size_t)2 * ROWS * PB * 2;
+  static constexpr size_t y_bytes = (size_t)ROWS * PY * 4;
   // two hi/lo images: the A tile (reused as the fp32 y tile of phase 4) and the hidden tile
   static constexpr size_t a_bytes = split_bytes > y_bytes ? split_bytes : y_bytes;
   static constexpr size_t lds_bytes = a_bytes + split_bytes;
@@ -237,10 +240,10 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
   using C = MCfg<F>;
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
   __bf16 *thi = reinterpret_cast<__bf16 *>(lds_raw);                    // A tile, hi / lo
-  __bf16 *tlo = thi + kRows * C::PB;
+  __bf16 *tlo = thi + C::ROWS * C::PB;
   float *ytile = reinterpret_cast<float *>(lds_raw);                     // aliases the A tile (phase 4)
   __bf16 *hhi = reinterpret_cast<__bf16 *>(lds_raw + C::a_bytes);        // hidden tile, hi / lo
-  __bf16 *hlo = hhi + kRows * C::PB;
+  __bf16 *hlo = hhi + C::ROWS * C::PB;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int mi = lane & 15, mh = lane >> 4;
   const int jw = wave % C::NJW, tt0 = wave / C::NJW;
@@ -283,8 +286,8 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
       p.e1 = rowptr[p.r1];
     } else {
       p.r0 = p.r1 = 0;
-      p.e0 = tile * kRows;
-      p.e1 = p.e0 + kRows < R ? p.e0 + kRows : R;
+      p.e0 = tile * C::ROWS;
+      p.e1 = p.e0 + C::ROWS < R ? p.e0 + C::ROWS : R;
     }
     p.w0 = p.e0;
   };
@@ -361,8 +364,8 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     // ---- the pass after this one: its rows and indices travel while this one computes -------------
     Pass fol = cur;
     bool more = true;
-    if (cur.w0 + kRows < cur.e1) {
-      fol.w0 = cur.w0 + kRows;                              // a tile longer than one pass
+    if (cur.w0 + C::ROWS < cur.e1) {
+      fol.w0 = cur.w0 + C::ROWS;                             // a tile longer than one pass
     } else if (nxt.tile != cur.tile) {
       fol = nxt;
     } else {
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
       for (int32_t r = cur.r0 + t / C::Q; r < cur.r1; r += C::SLOTS) {
         const int32_t s = seg_s, en = seg_e;
         const int32_t lo = s > w0 ? s : w0;
-        const int32_t hi = en < w0 + kRows ? en : w0 + kRows;
+        const int32_t hi = en < w0 + C::ROWS ? en : w0 + C::ROWS;
         float *dst = agg + (int64_t)r * F + 4 * q;
         if (lo < hi) {
           float4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -506,7 +509,7 @@ int launch(const float *A, const float *W1, const float *G1, const int32_t *idx1
     W1 = reinterpret_cast<const float *>(img1);
     W2 = reinterpret_cast<const float *>(img2);
   }
-  const int64_t tiles = seg ? n_tiles : (R + kRows - 1) / kRows;
+  const int64_t tiles = seg ? n_tiles : (R + C::ROWS - 1) / C::ROWS;
   // W1 and W2 (2 x 16 F^2 bytes per block) are fetched once per block: one resident set of blocks
   // walks the tiles, each prefetching its next pass while it computes the current one
   static int per_cu = 0;
@@ -551,6 +554,11 @@ extern "C" int gwen_mlp2_supported(int64_t F) {
   return F == 32 || F == 64 || F == 128 || F == 256 ? 1 : 0;
 }
 
+extern "C" int gwen_mlp2_rows(int64_t F) {
+  return F == 32 ? MCfg<32>::ROWS : F == 64 ? MCfg<64>::ROWS : F == 128 ? MCfg<128>::ROWS
+       : F == 256 ? MCfg<256>::ROWS : GWEN_EINVAL;
+}
+
 extern "C" int64_t gwen_mlp2_workspace_bytes(int64_t F) {
   if (!gwen_mlp2_supported(F)) return GWEN_EINVAL;
   return F > 128 ? 2 * 2 * F * F * 2 : 0;      // two matrices x (hi, lo) x bf16
@@ -563,8 +571,8 @@ extern "C" int64_t gwen_edge_tiles_count(int64_t E, int64_t T) {
 
 extern "C" int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int64_t T,
                                int32_t *tile_row, int32_t *dst, gwen_stream_t stream_) {
-  if (N < 0 || E < 0 || T < 1 || T > kRows) return GWEN_EINVAL;
-  if (N >= (int64_t(1) << 31) - 1 || E >= (int64_t(1) << 31) - kRows) return GWEN_ERANGE;
+  if (N < 0 || E < 0 || T < 1 || T > kMaxRows) return GWEN_EINVAL;
+  if (N >= (int64_t(1) << 31) - 1 || E >= (int64_t(1) << 31) - kMaxRows) return GWEN_ERANGE;
   if (!rowptr || !tile_row || (E > 0 && !dst)) return GWEN_EINVAL;
   const int64_t n_tiles = gwen_edge_tiles_count(E, T);
   hipStream_t st = gwen_stream(stream_);
@@ -587,7 +595,7 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
   if (act != GWEN_ACT_NONE && act != GWEN_ACT_RELU && act != GWEN_ACT_SILU) return GWEN_EINVAL;
   if (agg && (!rowptr || !tile_row || n_tiles < 1)) return GWEN_EINVAL;
   if (!agg && !out) return R == 0 ? GWEN_OK : GWEN_EINVAL;
-  if (R >= (int64_t(1) << 31) - kRows || N_agg >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
+  if (R >= (int64_t(1) << 31) - kMaxRows || N_agg >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
   if (R == 0) {                      // no rows: every target's sum is empty
     if (agg && N_agg > 0) GWEN_HIP_CHECK(hipMemsetAsync(agg, 0, (size_t)N_agg * F * 4, st));

@@ -20,8 +20,8 @@ Edge features live in the graph's STORED order (targets ascending): ``EdgeGraph.
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass
-from typing import Optional, Tuple
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -30,12 +30,11 @@ from . import _lib, ops
 from .graph import GraphCSR, _ptr, _stream, prepare_bipartite
 
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "silu": _lib.ACT_SILU}
-_ROWS = 64          # rows per K6 pass
 
 
 @dataclass
 class EdgeGraph:
-    """Target-sorted edge list + the row-aligned tiling K6 walks (include/gwen_hip.h, gwen_edge_tiles)."""
+    """Target-sorted edge list + the row-aligned tilings K6 walks (include/gwen_hip.h, gwen_edge_tiles)."""
 
     num_src: int
     num_dst: int
@@ -44,12 +43,26 @@ class EdgeGraph:
     src: Tensor           # int32 [E]  source node of stored edge k
     dst: Tensor           # int32 [E]  target node of stored edge k
     eid: Tensor           # int32 [E]  position of stored edge k in the edge_index it came from
-    tile_row: Tensor      # int32 [n_tiles + 1]
-    n_tiles: int
+    max_degree: int       # longest target row
+    _tiles: Dict[int, Tuple[Tensor, int]] = field(default_factory=dict, repr=False)
 
     @property
     def device(self) -> torch.device:
         return self.rowptr.device
+
+    def tiles(self, rows: int) -> Tuple[Tensor, int]:
+        """(tile_row int32 [n_tiles + 1], n_tiles) for a kernel that takes ``rows`` rows per pass: the
+        tile size rows - (max_degree - 1) makes every tile a single pass on bounded-degree graphs."""
+        if rows not in self._tiles:
+            t = max(rows - max(self.max_degree - 1, 0), rows // 2) if self.max_degree <= rows else rows
+            n_tiles = int(_lib.lib().gwen_edge_tiles_count(self.num_edges, t))
+            tile_row = torch.empty(n_tiles + 1, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().gwen_edge_tiles(_ptr(self.rowptr), self.num_dst, self.num_edges, t,
+                                                _ptr(tile_row), _ptr(self.dst), _stream(self.device))
+            _lib.check(rc, "gwen_edge_tiles")
+            self._tiles[rows] = (tile_row, n_tiles)
+        return self._tiles[rows]
 
     def sort_edges(self, e: Tensor) -> Tensor:
         """Edge features in ``edge_index`` order -> stored order."""
@@ -62,20 +75,15 @@ class EdgeGraph:
 
 
 def interaction_graph(edge_index: Tensor, num_src: int, num_dst: int) -> EdgeGraph:
-    """Once per graph: sort by target (K1, gwen_gcn_prep_rect) and tile (gwen_edge_tiles)."""
+    """Once per graph: sort by target (K1, gwen_gcn_prep_rect); tilings are cut on first use."""
     g: GraphCSR = prepare_bipartite(edge_index, num_src, num_dst, mean=False)
     e, dev = g.num_edges, g.device
-    # one read-back per graph: the longest row decides the tile size (a tile = one 64-row pass)
+    # one read-back per graph: the longest row decides the tile size (a tile = one pass of the kernel)
     max_deg = int((g.rowptr[1:] - g.rowptr[:-1]).max().item()) if num_dst > 0 else 0
-    t = max(_ROWS - max(max_deg - 1, 0), _ROWS // 2) if max_deg <= _ROWS else _ROWS
-    n_tiles = int(_lib.lib().gwen_edge_tiles_count(e, t))
-    tile_row = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     dst = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        rc = _lib.lib().gwen_edge_tiles(_ptr(g.rowptr), num_dst, e, t, _ptr(tile_row), _ptr(dst),
-                                        _stream(dev))
-    _lib.check(rc, "gwen_edge_tiles")
-    return EdgeGraph(num_src, num_dst, e, g.rowptr, g.col[:e], dst[:e], g.eid[:e], tile_row, n_tiles)
+    graph = EdgeGraph(num_src, num_dst, e, g.rowptr, g.col[:e], dst[:e], g.eid[:e], max_deg)
+    graph.tiles(64)              # also fills dst
+    return graph
 
 
 def mlp2_supported(channels: int) -> bool:
@@ -109,11 +117,12 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
         raise ValueError("res must have the shape of A")
     dev = a.device
     out = torch.empty_like(a) if want_out else None
-    agg = None
+    agg, tile_row, n_tiles = None, None, 0
     if graph is not None:
         if graph.num_edges != rows:
             raise ValueError("A must hold one row per stored edge of the graph")
         agg = torch.empty(graph.num_dst, f, dtype=torch.float32, device=dev)
+        tile_row, n_tiles = graph.tiles(int(_lib.lib().gwen_mlp2_rows(f)))
     nws = int(_lib.lib().gwen_mlp2_workspace_bytes(f))
     ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws > 0 else None
     with torch.cuda.device(dev):
@@ -121,8 +130,8 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
             _ptr(a), _ptr(w1), _ptr(g1), _ptr(idx1), 0 if g1 is None else g1.size(0),
             _ptr(g2), _ptr(idx2), 0 if g2 is None else g2.size(0), _ptr(b1), _ptr(w2), _ptr(b2),
             _ptr(res), _ptr(out), rows, f, _ACT[act],
-            _ptr(graph.rowptr) if graph else None, _ptr(graph.tile_row) if graph else None,
-            graph.n_tiles if graph else 0, _ptr(agg), graph.num_dst if graph else 0, int(mean),
+            _ptr(graph.rowptr) if graph else None, _ptr(tile_row), n_tiles, _ptr(agg),
+            graph.num_dst if graph else 0, int(mean),
             _ptr(ws), nws, _stream(dev))
     _lib.check(rc, "gwen_mlp2_f32")
     return out, agg

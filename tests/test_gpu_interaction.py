@@ -36,8 +36,9 @@ def _graphs(ga):
     }
 
 
+@pytest.mark.parametrize("rows", [64, 32])
 @pytest.mark.parametrize("name", ["mesh", "g2m", "m2g", "K125", "multi", "sparse", "star", "empty", "one_edge"])
-def test_edge_tiles_are_row_aligned(ga, name):
+def test_edge_tiles_are_row_aligned(ga, name, rows):
     from gwen_amd.interaction import interaction_graph
     ns, nd, ei = _graphs(ga)[name]
     g = interaction_graph(ei.to(DEV), ns, nd)
@@ -53,12 +54,17 @@ def test_edge_tiles_are_row_aligned(ga, name):
     assert np.array_equal(g.dst.cpu().numpy(), ei[1].numpy()[eid])
     # tiles: contiguous row ranges covering every row once; tile c starts at the first row whose
     # first edge is at or after c T
-    tr = g.tile_row.cpu().numpy()
-    assert tr[0] == 0 and tr[-1] == nd and np.all(np.diff(tr) >= 0) and len(tr) == g.n_tiles + 1
+    tile_row, n_tiles = g.tiles(rows)
+    tr = tile_row.cpu().numpy()
+    assert tr[0] == 0 and tr[-1] == nd and np.all(np.diff(tr) >= 0) and len(tr) == n_tiles + 1
     max_deg = int(np.diff(rp).max()) if nd else 0
+    assert g.max_degree == max_deg
     spans = rp[tr[1:]] - rp[tr[:-1]]
-    if max_deg <= 33:
-        assert spans.max() <= 64                         # a tile is a single 64-row pass
+    if max_deg <= rows // 2 + 1:
+        assert spans.max() <= rows                       # a tile is a single pass of the kernel
+    t = max(rows - max(max_deg - 1, 0), rows // 2) if max_deg <= rows else rows
+    firsts = rp[tr[:-1]]                                 # tile c starts at the first row at or after c T
+    assert all(firsts[c] >= c * t and (tr[c] == 0 or rp[tr[c] - 1] < c * t) for c in range(1, n_tiles))
     x = torch.randn(e, 3)
     assert torch.equal(g.unsort_edges(g.sort_edges(x.to(DEV))).cpu(), x)
 

@@ -66,7 +66,7 @@ def main():
     # algorithmic bytes of the edge launch: e read + e' write + two gathered rows + agg write + indices
     b_alg = 4 * F * (4 * E + nd) + 8 * E + 4 * nd
     flops = 4 * F * F * E                     # two F x F contractions per edge, fp32-equivalent
-    print(f"graph {args.graph}: Ns={ns} Nd={nd} E={E} F={F} tiles={g.n_tiles}")
+    print(f"graph {args.graph}: Ns={ns} Nd={nd} E={E} F={F} max_degree={g.max_degree}")
     print(f"node projection (K3)        {t_proj:8.1f} us")
     print(f"edge MLP + aggregate (K6)   {t_edge:8.1f} us   {b_alg / t_edge / 1e3:7.1f} GB/s algorithmic, "
           f"{flops / t_edge / 1e6:6.1f} TFLOP/s fp32-equivalent ({3 * flops / t_edge / 1e6:6.1f} bf16 issued), "
