@@ -34,10 +34,10 @@ class LaunchInfo(C.Structure):
 
 
 ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
-KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN = 2, 3, 4, 5
+KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN, KIND_SMALL = 2, 3, 4, 5, 6
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer",
-              KIND_CHAIN: "chain"}
+              KIND_CHAIN: "chain", KIND_SMALL: "small"}
 
 # name -> (restype, argtypes); mirrors include/gwen_hip.h one to one
 SIGNATURES = {
@@ -63,7 +63,7 @@ SIGNATURES = {
     "gwen_gcn_chain_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,
                                   _int, _i64, _i64, _i64, _vp]),
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
-    "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
+    "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
                                     C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]),
     "gwen_event_create": (_int, [C.POINTER(C.c_void_p)]),
@@ -75,6 +75,10 @@ SIGNATURES = {
     "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "gwen_relu_backward_f32": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gwen_gcn_small_supported": (_int, [_i64, _i64, _i64]),
+    "gwen_gcn_small_workspace_floats": (_i64, [_i64, _i64, _i64, _i64]),
+    "gwen_gcn_dense_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "gwen_gcn_small_layer_f32": (_int, [_vp] * 5 + [_i64] * 6 + [_int, _vp, _i64, _vp]),
     "gwen_mlp2_supported": (_int, [_i64]),
     "gwen_edge_tiles_count": (_i64, [_i64, _i64]),
     "gwen_edge_tiles": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -43,6 +43,8 @@ int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t
   for (int32_t i = 0; i < n; ++i) {
     const int64_t w = gwen_gcn_linear_workspace_floats(rows, layers[i].fin, layers[i].fout);
     if (w > lin_w) lin_w = w;
+    const int64_t w7 = gwen_gcn_small_workspace_floats(N, members, layers[i].fin, layers[i].fout);
+    if (w7 > lin_w) lin_w = w7;               // K7's split-K partials share the region
   }
   P->ping = 0;
   P->pong = round4(rows * out_w);
@@ -65,8 +67,8 @@ extern "C" int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members,
 
 extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                                     const int32_t *g_rowptr, const int32_t *g_col,
-                                    const float *g_val, int64_t N, const gwen_layer_desc *layers,
-                                    int32_t n_layers,
+                                    const float *g_val, const float *dense, int64_t N,
+                                    const gwen_layer_desc *layers, int32_t n_layers,
                                     const float *x, float *out, float *scratch,
                                     int64_t scratch_floats, int64_t members, gwen_stream_t stream,
                                     void **events, gwen_launch_info *info, int32_t max_launches,
@@ -104,6 +106,24 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
   const bool have_grouped = g_col && g_val;          // g_rowptr NULL = uniform layout
 
   const float *cur = x;
+  // small graph, wide features (the reference's own shape): every layer is one K7 launch
+  bool small = dense != nullptr;
+  for (int32_t i = 0; i < n_layers && small; ++i)
+    small = layers[i].order == GWEN_ORDER_AUTO &&
+            gwen_gcn_small_supported(N, layers[i].fin, layers[i].fout);
+  if (small) {
+    for (int32_t i = 0; i < n_layers; ++i) {
+      const gwen_layer_desc &L = layers[i];
+      float *dst = i + 1 == n_layers ? out : buf[i & 1];
+      GWEN_TRY(before(GWEN_KIND_SMALL, i, L.fin, L.fout));
+      GWEN_TRY(gwen_gcn_small_layer_f32(dense, cur, L.W, L.bias, dst, N, L.fin, L.fout, members,
+                                        N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats, stream));
+      GWEN_TRY(after());
+      cur = dst;
+    }
+    if (n_launches) *n_launches = nl;
+    return GWEN_OK;
+  }
   bool projected = false;          // cur holds h_i = a_i W_i^T (layer i's bias/ReLU still pending)
   int32_t nbuf = 0;
   for (int32_t i = 0; i < n_layers; ++i) {

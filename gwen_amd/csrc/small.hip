@@ -1,0 +1,330 @@
+// K7 -- one whole GCNConv layer on a SMALL graph (N <= 128 nodes) with WIDE features, the shape of the
+// reference's own workload: its graph is the complete graph over ~125-150 ensemble members
+// (/root/reference/src/gwen/utils.py:175-176) and its features are flattened fields, C = height x
+// ncells -> hidden 1024 (/root/reference/src/gwen/config.json:9,12; layers
+// /root/reference/src/gwen/models_gnn.py:118-130,:172-184).  At that shape K3 + K2 are latency-bound:
+// a 125-row projection is 2-8 blocks of the 128 x 128 tile kernel (18-30 us each) and every propagate
+// walks 125-entry rows 8 entries per memory round trip (14-17 us each): 272 us per forward.
+//
+// Here the normalised adjacency is a dense 128 x 128 matrix D (zero padded, built once per graph by
+// gwen_gcn_dense_f32) and a layer is two chained contractions per block of output columns,
+//        h[:, cols] = x W[cols, :]^T          (K = Fin, streamed from global memory, no LDS)
+//        out[:, cols] = act( D h[:, cols] + b[cols] )      (K = 128, h through LDS, transposed)
+// both as 3xbf16 split MFMAs with fp32 accumulation (see layer.hip).  Only the summation ORDER differs
+// from the sequential edge-order sum of K2 (fp32 rounding; parity tolerance 1e-4 as everywhere).
+//   block = 4 waves = all 128 (padded) rows x BN = 16 NC output columns; wave w owns row tiles 2w, 2w+1;
+//   W is the MFMA A operand, x the B operand, both read straight from global memory in fragment layout
+//   (8 consecutive floats per lane = 32 B, 128 B contiguous per row per k-step) one k-step ahead;
+//   a long K (the C -> 1024 projection) is cut over blockIdx.z: partial h tiles go to a workspace and
+//   k_small_finish adds them in split order before the second contraction.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kNP = 128;                  // padded node count (8 row tiles)
+constexpr int kPJ = kNP + 8;              // pitch of the transposed h tile (bf16): conflict-free 16-B reads
+
+__device__ inline void split8(const float4_t a, const float4_t b, bf16x8 &hi, bf16x8 &lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+
+__device__ inline f32x4 mma3(const bf16x8 ahi, const bf16x8 alo, const bf16x8 bhi, const bf16x8 blo,
+                             f32x4 d) {
+  d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi, d, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi, d, 0, 0, 0);
+}
+
+// second contraction + bias + ReLU + store, from the h tile this lane holds in D layout
+// (d[rt][n]: row (2 wave + rt) 16 + mi, columns c0 + 16 n + 4 mh .. +3)
+template <int NC>
+__device__ inline void aggregate_store(f32x4 (&d)[2][NC], const float *__restrict__ dense,
+                                       const float *__restrict__ bias, float *__restrict__ om,
+                                       int N, int Fout, int c0, int relu, __bf16 *hthi, __bf16 *htlo) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
+  // this lane's fragments of D (rows of its two row tiles), requested before anything else: sixteen
+  // independent 16-B loads in flight instead of eight dependent round trips inside the MFMA loop
+  float4_t dr[kNP / 32][2][2];
+#pragma unroll
+  for (int ks = 0; ks < kNP / 32; ++ks)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float *dp = dense + ((2 * wave + rt) * 16 + mi) * kNP + 32 * ks + 8 * mh;
+      dr[ks][rt][0] = *reinterpret_cast<const float4_t *>(dp);
+      dr[ks][rt][1] = *reinterpret_cast<const float4_t *>(dp + 4);
+    }
+  // h^T into LDS (column-major: ht[c][j]), split once per element
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int j = (2 * wave + rt) * 16 + mi;
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = d[rt][n][i];
+        const __bf16 h = (__bf16)v;
+        const int c = 16 * n + 4 * mh + i;
+        hthi[c * kPJ + j] = h;
+        htlo[c * kPJ + j] = (__bf16)(v - (float)h);
+      }
+  }
+  __syncthreads();
+  f32x4 o[2][NC];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) o[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < kNP / 32; ++ks) {
+    bf16x8 ahi[NC], alo[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int off = (16 * n + mi) * kPJ + 32 * ks + 8 * mh;
+      ahi[n] = *reinterpret_cast<const bf16x8 *>(hthi + off);
+      alo[n] = *reinterpret_cast<const bf16x8 *>(htlo + off);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      bf16x8 bhi, blo;
+      split8(dr[ks][rt][0], dr[ks][rt][1], bhi, blo);
+#pragma unroll
+      for (int n = 0; n < NC; ++n) o[rt][n] = mma3(ahi[n], alo[n], bhi, blo, o[rt][n]);
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = (2 * wave + rt) * 16 + mi;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int c = c0 + 16 * n + 4 * mh;
+      float4_t v = {o[rt][n][0], o[rt][n][1], o[rt][n][2], o[rt][n][3]};
+      if (bias) v += *reinterpret_cast<const float4_t *>(bias + c);
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] < 0.0f ? 0.0f : v[i];
+      }
+      if (row < N) *reinterpret_cast<float4_t *>(om + (int64_t)row * Fout + c) = v;
+    }
+  }
+}
+
+template <int NC, bool SPLIT>
+__global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
+                                               const float *__restrict__ x,
+                                               const float *__restrict__ W,
+                                               const float *__restrict__ bias, float *__restrict__ out,
+                                               float *__restrict__ part, int N, int Fin, int Fout,
+                                               int kchunk, int relu, int64_t mstride_x,
+                                               int64_t mstride_o) {
+  __shared__ __attribute__((aligned(16))) __bf16 ht[SPLIT ? 8 : 2 * 16 * NC * kPJ];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
+  const int c0 = blockIdx.x * 16 * NC, member = blockIdx.y;
+  const int k0 = blockIdx.z * kchunk, k1 = k0 + kchunk < Fin ? k0 + kchunk : Fin;
+  const float *xp[2], *wp[NC];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    int row = (2 * wave + rt) * 16 + mi;
+    row = row < N ? row : N - 1;                  // padded rows repeat the last one (finite values)
+    xp[rt] = x + member * mstride_x + (int64_t)row * Fin + 8 * mh;
+  }
+#pragma unroll
+  for (int n = 0; n < NC; ++n) wp[n] = W + (int64_t)(c0 + 16 * n + mi) * Fin + 8 * mh;
+
+  f32x4 d[2][NC];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) d[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // KU k-steps are in flight at any time: slot u is re-requested (KU steps ahead) as soon as its
+  // values have been split -- with one step ahead the 32-deep loop ran at one memory round trip per
+  // step (27 us for 1024 -> 512 on 125 rows)
+  constexpr int KU = NC == 1 ? 4 : 2;
+  float4_t xr[KU][2][2], wr[KU][NC][2];
+  auto fetch = [&](int u, int k) {
+    k = k < k1 ? k : k1 - 32;                       // unconditional load, clamped into the range
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      xr[u][rt][0] = *reinterpret_cast<const float4_t *>(xp[rt] + k);
+      xr[u][rt][1] = *reinterpret_cast<const float4_t *>(xp[rt] + k + 4);
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      wr[u][n][0] = *reinterpret_cast<const float4_t *>(wp[n] + k);
+      wr[u][n][1] = *reinterpret_cast<const float4_t *>(wp[n] + k + 4);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < KU; ++u) fetch(u, k0 + 32 * u);
+#pragma unroll 1
+  for (int k = k0; k < k1; k += 32 * KU) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      bf16x8 xhi[2], xlo[2], whi[NC], wlo[NC];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) split8(xr[u][rt][0], xr[u][rt][1], xhi[rt], xlo[rt]);
+#pragma unroll
+      for (int n = 0; n < NC; ++n) split8(wr[u][n][0], wr[u][n][1], whi[n], wlo[n]);
+      fetch(u, k + 32 * (KU + u));
+      if (k + 32 * u < k1) {                        // uniform: the range need not be a multiple of KU
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) d[rt][n] = mma3(whi[n], wlo[n], xhi[rt], xlo[rt], d[rt][n]);
+      }
+    }
+  }
+  if constexpr (SPLIT) {
+    float *pm = part + ((int64_t)blockIdx.z * gridDim.y + member) * N * Fout;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = (2 * wave + rt) * 16 + mi;
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+        if (row < N)
+          *reinterpret_cast<float4_t *>(pm + (int64_t)row * Fout + c0 + 16 * n + 4 * mh) =
+              float4_t{d[rt][n][0], d[rt][n][1], d[rt][n][2], d[rt][n][3]};
+    }
+  } else {
+    aggregate_store<NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
+                        ht + 16 * NC * kPJ);
+  }
+}
+
+// adds the partial h tiles in split order, then the second contraction
+template <int NC>
+__global__ __launch_bounds__(256) void k_small_finish(const float *__restrict__ dense,
+                                                      const float *__restrict__ part,
+                                                      const float *__restrict__ bias,
+                                                      float *__restrict__ out, int N, int Fout,
+                                                      int nsplit, int relu, int64_t mstride_o) {
+  __shared__ __attribute__((aligned(16))) __bf16 ht[2 * 16 * NC * kPJ];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
+  const int c0 = blockIdx.x * 16 * NC, member = blockIdx.y;
+  f32x4 d[2][NC];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    int row = (2 * wave + rt) * 16 + mi;
+    row = row < N ? row : N - 1;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      float4_t acc = {0.f, 0.f, 0.f, 0.f};
+      const float *pp = part + (int64_t)member * N * Fout + (int64_t)row * Fout + c0 + 16 * n + 4 * mh;
+      const int64_t ss = (int64_t)gridDim.y * N * Fout;
+      for (int s = 0; s < nsplit; s += 8) {          // 8 partials in flight, added in split order
+        float4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = *reinterpret_cast<const float4_t *>(pp + (s + u < nsplit ? s + u : nsplit - 1) * ss);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s + u < nsplit) acc += v[u];
+      }
+      d[rt][n] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    }
+  }
+  aggregate_store<NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
+                      ht + 16 * NC * kPJ);
+}
+
+// dense[i][j] = sum of the stored weights of entries (i <- j), zero elsewhere; one thread per row adds
+// its entries in stored order (multi-edges accumulate deterministically)
+__global__ void k_dense(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                        const float *__restrict__ val, int N, float *__restrict__ dense) {
+  const int i = blockIdx.x, j = threadIdx.x;            // kNP blocks x kNP threads
+  __shared__ float row[kNP];
+  row[j] = 0.0f;
+  __syncthreads();
+  if (j == 0 && i < N)
+    for (int32_t s = rowptr[i]; s < rowptr[i + 1]; ++s) row[col[s]] += val[s];
+  __syncthreads();
+  dense[i * kNP + j] = row[j];
+}
+
+struct Shape {
+  int nc, nsplit, kchunk;
+};
+
+inline Shape shape_for(int64_t Fin, int64_t Fout) {
+  Shape s;
+  // wide blocks (64 columns) re-read x a quarter as often: worth it when x is large (long K) or when
+  // there are plenty of column blocks anyway
+  s.nc = (Fout % 64 == 0 && (Fin >= 4096 || Fout >= 4096)) ? 4 : 1;
+  const int64_t blocks = Fout / (16 * s.nc);
+  // K is cut over blocks whenever the column blocks alone leave most CUs idle: a block then walks at
+  // least 128 of K (4 k-steps) and the partial tiles are added by k_small_finish
+  int64_t n = 1;
+  if (Fin >= 512 && blocks < 256) {
+    n = (256 + blocks - 1) / blocks;                     // aim at ~256 blocks ...
+    if (Fin >= 4096) n *= 2;                             // ... ~512 when K is very long
+    if (n > Fin / 128) n = Fin / 128;
+    if (n < 1) n = 1;
+  }
+  s.kchunk = (int)(((Fin + n - 1) / n + 31) / 32 * 32);
+  s.nsplit = (int)((Fin + s.kchunk - 1) / s.kchunk);
+  return s;
+}
+
+}  // namespace
+
+extern "C" int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout) {
+  return N >= 1 && N <= kNP && Fin >= 32 && Fin % 32 == 0 && Fout >= 16 && Fout % 16 == 0 ? 1 : 0;
+}
+
+extern "C" int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin,
+                                                   int64_t Fout) {
+  if (!gwen_gcn_small_supported(N, Fin, Fout) || members < 0) return 0;
+  const Shape s = shape_for(Fin, Fout);
+  return s.nsplit > 1 ? (int64_t)s.nsplit * members * N * Fout : 0;
+}
+
+extern "C" int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                                  int64_t N, float *dense, gwen_stream_t stream_) {
+  if (N < 1 || N > kNP || !rowptr || !col || !val || !dense) return GWEN_EINVAL;
+  k_dense<<<kNP, kNP, 0, gwen_stream(stream_)>>>(rowptr, col, val, (int)N, dense);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+extern "C" int gwen_gcn_small_layer_f32(const float *dense, const float *x, const float *W,
+                                        const float *bias, float *out, int64_t N, int64_t Fin,
+                                        int64_t Fout, int64_t members, int64_t mstride_x,
+                                        int64_t mstride_o, int relu, float *workspace,
+                                        int64_t workspace_floats, gwen_stream_t stream_) {
+  if (members < 0 || !gwen_gcn_small_supported(N, Fin, Fout)) return GWEN_EINVAL;
+  if (members == 0) return GWEN_OK;
+  if (!dense || !x || !W || !out || x == out || members > 65535) return GWEN_EINVAL;
+  const void *al[] = {dense, x, W, bias, out, workspace};
+  for (const void *p : al)
+    if (p && !gwen_aligned(p, 16)) return GWEN_EINVAL;
+  if (mstride_x % 4 || mstride_o % 4) return GWEN_EINVAL;
+  const Shape s = shape_for(Fin, Fout);
+  if (s.nsplit > 1 && (!workspace || workspace_floats < (int64_t)s.nsplit * members * N * Fout))
+    return GWEN_ENOSPACE;
+  hipStream_t st = gwen_stream(stream_);
+  const dim3 grid((unsigned)(Fout / (16 * s.nc)), (unsigned)members, (unsigned)s.nsplit);
+  const dim3 fgrid((unsigned)(Fout / 16), (unsigned)members);   // the finish always 16 columns a block
+#define GWEN_S(NCV)                                                                                  \
+  if (s.nc == NCV) {                                                                                 \
+    if (s.nsplit > 1) {                                                                              \
+      k_small<NCV, true><<<grid, 256, 0, st>>>(dense, x, W, bias, out, workspace, (int)N, (int)Fin,   \
+                                               (int)Fout, s.kchunk, relu, mstride_x, mstride_o);     \
+      k_small_finish<1><<<fgrid, 256, 0, st>>>(dense, workspace, bias, out, (int)N, (int)Fout,        \
+                                               s.nsplit, relu, mstride_o);                           \
+    } else {                                                                                         \
+      k_small<NCV, false><<<grid, 256, 0, st>>>(dense, x, W, bias, out, nullptr, (int)N, (int)Fin,    \
+                                                (int)Fout, s.kchunk, relu, mstride_x, mstride_o);    \
+    }                                                                                                \
+  }
+  GWEN_S(1) GWEN_S(4)
+#undef GWEN_S
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}

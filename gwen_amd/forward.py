@@ -147,7 +147,8 @@ class StackForward:
         gr, gc, gv = g.grouped()
         with torch.cuda.device(dev):
             rc = _lib.lib().gwen_gnn_forward_f32(
-                _ptr(g.rowptr), _ptr(g.col), _ptr(g.val), _ptr(gr), _ptr(gc), _ptr(gv), n, self.desc, len(self.desc), _ptr(x),
+                _ptr(g.rowptr), _ptr(g.col), _ptr(g.val), _ptr(gr), _ptr(gc), _ptr(gv), _ptr(g.dense()), n,
+                self.desc, len(self.desc), _ptr(x),
                 _ptr(out), _ptr(scratch), scratch.numel(), members, _stream(dev),
                 None if events is None else events._ev,
                 None if events is None else events.info,

@@ -46,6 +46,7 @@ class GraphCSR:
     _workspace: Optional[Tensor] = field(default=None, repr=False)
     _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
     _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
+    _dense: Optional[Tensor] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -65,6 +66,20 @@ class GraphCSR:
         if self._grouped is None:
             self._grouped = _grouped_impl(self)
         return self._grouped
+
+    def dense(self) -> Optional[Tensor]:
+        """The graph as a dense 128 x 128 fp32 matrix for K7 (square graphs of at most 128 nodes: the
+        reference's member graphs); None for larger or bipartite graphs.  Built on first use."""
+        if self.num_src >= 0 or not 1 <= self.num_nodes <= 128:
+            return None
+        if self._dense is None:
+            d = torch.empty(128 * 128, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().gwen_gcn_dense_f32(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
+                                                   self.num_nodes, _ptr(d), _stream(self.device))
+            _lib.check(rc, "gwen_gcn_dense_f32")
+            self._dense = d
+        return self._dense
 
     def transposed(self) -> Tuple[Tensor, Tensor, Tensor]:
         """CSR by SOURCE node (rowptr, col = target, val) for the backward pass; built on first use."""

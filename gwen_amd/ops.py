@@ -122,6 +122,34 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     return out
 
 
+def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
+                relu: bool = False) -> Tensor:
+    """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 128 nodes (dense adjacency)."""
+    _require(x, "x")
+    _require(weight, "weight")
+    x, weight = x.contiguous(), weight.contiguous()
+    m, n_src, fin = _rows2d(x)
+    n, fout = graph.num_nodes, weight.size(0)
+    dense = graph.dense()
+    if dense is None or not _lib.lib().gwen_gcn_small_supported(n, fin, fout):
+        raise ValueError("K7 needs a square graph of at most 128 nodes, Fin % 32 == 0, Fout % 16 == 0")
+    if n_src != n or weight.size(1) != fin:
+        raise ValueError("shape mismatch between x, weight and the graph")
+    if bias is not None:
+        _require(bias, "bias")
+        bias = bias.contiguous()
+    dev = x.device
+    out = torch.empty(*x.shape[:-2], n, fout, dtype=torch.float32, device=dev)
+    nws = int(_lib.lib().gwen_gcn_small_workspace_floats(n, m, fin, fout))
+    ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws > 0 else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_small_layer_f32(_ptr(dense), _ptr(x), _ptr(weight), _ptr(bias), _ptr(out),
+                                                 n, fin, fout, m, n * fin, n * fout, int(relu), _ptr(ws),
+                                                 nws, _stream(dev))
+    _lib.check(rc, "gwen_gcn_small_layer_f32")
+    return out
+
+
 def chain(graph: GraphCSR, x: Tensor, w1: Tensor, w2: Optional[Tensor], bias: Optional[Tensor],
           relu: bool, pre: bool) -> Tensor:
     """K5.  pre=False: act((A~ x) w1^T + bias) w2^T;  pre=True: act(A~ x + bias) w1^T  (inference only)."""

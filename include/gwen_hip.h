@@ -165,6 +165,8 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
  *   then K3) when fin < fout.  Explicit orders are taken literally, layer by layer.
  * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4/K5 layers;
  *   g_col/g_val may be NULL when no layer resolves to K4/K5, g_rowptr NULL = uniform layout).
+ * dense: the graph as a dense 128 x 128 matrix (gwen_gcn_dense_f32) or NULL; when given and every
+ *   layer is AUTO and gwen_gcn_small_supported(N, fin, fout), every layer is ONE K7 launch.
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
  * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
  * events (HOST array of hipEvent_t, or NULL): if given, events[2i] / events[2i+1] are recorded on
@@ -180,6 +182,7 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
 #define GWEN_KIND_PROPAGATE 2   /* K2 */
 #define GWEN_KIND_LAYER 4       /* K4 */
 #define GWEN_KIND_CHAIN 5       /* K5: info.fin = gathered width, info.fout = stored width */
+#define GWEN_KIND_SMALL 6       /* K7: whole layer on a small graph (dense adjacency) */
 
 typedef struct gwen_layer_desc {
   const float *W;
@@ -194,11 +197,33 @@ typedef struct gwen_launch_info {
 int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members, const gwen_layer_desc *layers,
                                         int32_t n_layers);
 int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
-                         const int32_t *g_rowptr, const int32_t *g_col, const float *g_val, int64_t N,
-                         const gwen_layer_desc *layers, int32_t n_layers, const float *x, float *out,
+                         const int32_t *g_rowptr, const int32_t *g_col, const float *g_val,
+                         const float *dense, int64_t N, const gwen_layer_desc *layers,
+                         int32_t n_layers, const float *x, float *out,
                          float *scratch, int64_t scratch_floats, int64_t members,
                          gwen_stream_t stream, void **events, gwen_launch_info *info,
                          int32_t max_launches, int32_t *n_launches);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  a whole GCNConv layer on a SMALL graph (N <= 128) with wide features -- the reference's own
+ * shape: the complete graph over ~125-150 ensemble members (/root/reference/src/gwen/utils.py:175-176),
+ * features = flattened fields, hidden 1024 (/root/reference/src/gwen/config.json:9,12).
+ *   gwen_gcn_dense_f32: dense[i*128 + j] = sum of the stored weights of entries (i <- j) of a prepared
+ *     square CSR (K1), zero elsewhere; dense: fp32 [128*128].
+ *   gwen_gcn_small_layer_f32: out[m] = act( dense (x[m] W^T) + bias ), x [members, N, Fin] contiguous
+ *     rows (member stride mstride_x), W [Fout, Fin], out [members, N, Fout]; Fin % 32 == 0,
+ *     Fout % 16 == 0 (gwen_gcn_small_supported).  3xbf16 contractions, fp32 accumulation; the
+ *     aggregation is a dense contraction, so only the summation order differs from K2's.
+ *     workspace: gwen_gcn_small_workspace_floats() fp32 elements (0 unless K is cut over blocks).
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout);
+int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin, int64_t Fout);
+int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+                       float *dense, gwen_stream_t stream);
+int gwen_gcn_small_layer_f32(const float *dense, const float *x, const float *W, const float *bias,
+                             float *out, int64_t N, int64_t Fin, int64_t Fout, int64_t members,
+                             int64_t mstride_x, int64_t mstride_o, int relu, float *workspace,
+                             int64_t workspace_floats, gwen_stream_t stream);
 
 /* hipEvent plumbing for callers without a HIP binding (bench.py times kernels with these, on the
  * stream the kernels are launched on). */

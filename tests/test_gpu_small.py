@@ -1,0 +1,92 @@
+"""K7 (gwen_gcn_small_layer_f32, gwen_gcn_dense_f32): whole GCNConv layers on graphs of at most 128 nodes
+with wide features -- the reference's own shape (complete graph over ~125 members,
+/root/reference/src/gwen/utils.py:175-176; hidden 1024, config.json:12) -- against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import REL_TOL, SEED, graph_cases, make_params, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SMALL = [c for c in graph_cases() if c[1] <= 128]
+
+
+@pytest.fixture(scope="module")
+def ga(hip_lib):
+    import gwen_amd
+    return gwen_amd
+
+
+@pytest.mark.parametrize("name,n,ei", SMALL, ids=[c[0] for c in SMALL])
+def test_dense_matrix_is_the_normalised_adjacency(ga, name, n, ei):
+    from oracle import gcn_oracle as O
+    g = ga.prepare_graph(ei.to(DEV), n)
+    d = g.dense().cpu().view(128, 128)
+    ei2, w = O.gcn_norm(ei, None, n)
+    want = torch.zeros(128, 128, dtype=torch.float64)
+    want.index_put_((ei2[1], ei2[0]), w.double(), accumulate=True)
+    assert rel_err(d, want) <= 1e-6
+    assert torch.count_nonzero(d[n:]) == 0 and torch.count_nonzero(d[:, n:]) == 0
+
+
+@pytest.mark.parametrize("name,n,ei", SMALL, ids=[c[0] for c in SMALL])
+@pytest.mark.parametrize("fin,fout", [(32, 16), (64, 64), (1024, 512), (4096, 64), (8192, 128), (64, 4096)])
+@pytest.mark.parametrize("members,relu,use_bias", [(1, True, True), (3, False, False)])
+def test_small_layer_vs_oracle(ga, name, n, ei, fin, fout, members, relu, use_bias):
+    from gwen_amd import ops
+    from oracle import gcn_oracle as O
+    w, b = make_params(fin, fout)
+    g = torch.Generator().manual_seed(SEED + fin)
+    x = torch.randn(members, n, fin, generator=g)
+    want = torch.stack([O.gcn_conv(x[m].double(), ei, w.double(), b.double() if use_bias else None)
+                        for m in range(members)])
+    if relu:
+        want = torch.relu(want)
+    graph = ga.prepare_graph(ei.to(DEV), n)
+    xs = x.to(DEV) if members > 1 else x[0].to(DEV)
+    got = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu)
+    again = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu)
+    assert rel_err(got.view(members, n, fout), want) <= 2e-5
+    assert torch.equal(got, again)
+
+
+def test_reference_shaped_model_runs_on_k7(ga):
+    """GNNModel on the reference's graph family: every layer is one K7 launch, result within tolerance."""
+    from gwen_amd.mesh import complete_graph
+    from oracle import gcn_oracle as O
+    n, c, h = 125, 2048, 256
+    ei = torch.from_numpy(complete_graph(n))
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(n, n, c, c, h))
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    oracle = O.OracleGNNModel(O.OracleGNNConfig(n, n, c, c, h)).double()
+    oracle.load_state_dict({k: v.double() for k, v in model.state_dict().items()}, strict=True)
+    x = torch.randn(n, c, generator=torch.Generator().manual_seed(SEED))
+    with torch.no_grad():
+        want = oracle(x.double(), ei)
+    model = model.to(DEV).eval()
+    graph = model.prepare(ei.to(DEV), n)
+    plan = ga.StackForward(model.stack(), graph)
+    ev = ga.KernelEvents(12)
+    got = plan.run(x.to(DEV), events=ev)
+    kinds = [k for k, *_ in ev.durations()]
+    assert kinds == ["small"] * 6
+    assert rel_err(got, want) <= REL_TOL
+    with torch.no_grad():
+        assert torch.equal(model(x.to(DEV), ei.to(DEV)), got)
+
+
+def test_small_layer_rejects_what_it_cannot_do(ga):
+    from gwen_amd import ops
+    from helpers import random_multigraph
+    big = ga.prepare_graph(random_multigraph(300, 2000).to(DEV), 300)
+    assert big.dense() is None
+    with pytest.raises(ValueError):
+        ops.small_layer(big, torch.randn(300, 64, device=DEV), torch.randn(64, 64, device=DEV))
+    g = ga.prepare_graph(torch.tensor([[0, 1], [1, 0]], device=DEV), 2)
+    with pytest.raises(ValueError):
+        ops.small_layer(g, torch.randn(2, 24, device=DEV), torch.randn(16, 24, device=DEV))
