@@ -75,6 +75,7 @@ SIGNATURES = {
     "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "gwen_relu_backward_f32": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gwen_gcn_small_pad": (_int, [_i64]),
     "gwen_gcn_small_supported": (_int, [_i64, _i64, _i64]),
     "gwen_gcn_small_workspace_floats": (_i64, [_i64, _i64, _i64, _i64]),
     "gwen_gcn_dense_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -23,8 +23,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kNP = 128;                  // padded node count (8 row tiles)
-constexpr int kPJ = kNP + 8;              // pitch of the transposed h tile (bf16): conflict-free 16-B reads
+// NP = padded node count: 128 (2 row tiles per wave) or 256 (4); pitch of the transposed h tile
+// NP + 8 bf16 => conflict-free 16-B reads
+constexpr int kMaxNodes = 256;
+inline int pad_nodes(int64_t N) { return N <= 128 ? 128 : 256; }
 
 __device__ inline void split8(const float4_t a, const float4_t b, bf16x8 &hi, bf16x8 &lo) {
   const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -45,26 +47,28 @@ __device__ inline f32x4 mma3(const bf16x8 ahi, const bf16x8 alo, const bf16x8 bh
 
 // second contraction + bias + ReLU + store, from the h tile this lane holds in D layout
 // (d[rt][n]: row (2 wave + rt) 16 + mi, columns c0 + 16 n + 4 mh .. +3)
-template <int NC>
-__device__ inline void aggregate_store(f32x4 (&d)[2][NC], const float *__restrict__ dense,
+template <int NP, int NC>
+__device__ inline void aggregate_store(f32x4 (&d)[NP / 64][NC], const float *__restrict__ dense,
                                        const float *__restrict__ bias, float *__restrict__ om,
                                        int N, int Fout, int c0, int relu, __bf16 *hthi, __bf16 *htlo) {
+  constexpr int RT = NP / 64, PJ = NP + 8, KS = NP / 32;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
-  // this lane's fragments of D (rows of its two row tiles), requested before anything else: sixteen
-  // independent 16-B loads in flight instead of eight dependent round trips inside the MFMA loop
-  float4_t dr[kNP / 32][2][2];
+  // this lane's fragments of D (rows of its row tiles): the first k-step is requested before anything
+  // else, every later one a step ahead of the MFMAs that use it
+  float4_t dr[RT][2], dn[RT][2];
+  auto fetch_d = [&](int ks, float4_t (&r)[RT][2]) {
 #pragma unroll
-  for (int ks = 0; ks < kNP / 32; ++ks)
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const float *dp = dense + ((2 * wave + rt) * 16 + mi) * kNP + 32 * ks + 8 * mh;
-      dr[ks][rt][0] = *reinterpret_cast<const float4_t *>(dp);
-      dr[ks][rt][1] = *reinterpret_cast<const float4_t *>(dp + 4);
+    for (int rt = 0; rt < RT; ++rt) {
+      const float *dp = dense + ((RT * wave + rt) * 16 + mi) * NP + 32 * ks + 8 * mh;
+      r[rt][0] = *reinterpret_cast<const float4_t *>(dp);
+      r[rt][1] = *reinterpret_cast<const float4_t *>(dp + 4);
     }
+  };
+  fetch_d(0, dr);
   // h^T into LDS (column-major: ht[c][j]), split once per element
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int j = (2 * wave + rt) * 16 + mi;
+  for (int rt = 0; rt < RT; ++rt) {
+    const int j = (RT * wave + rt) * 16 + mi;
 #pragma unroll
     for (int n = 0; n < NC; ++n)
 #pragma unroll
@@ -72,36 +76,42 @@ __device__ inline void aggregate_store(f32x4 (&d)[2][NC], const float *__restric
         const float v = d[rt][n][i];
         const __bf16 h = (__bf16)v;
         const int c = 16 * n + 4 * mh + i;
-        hthi[c * kPJ + j] = h;
-        htlo[c * kPJ + j] = (__bf16)(v - (float)h);
+        hthi[c * PJ + j] = h;
+        htlo[c * PJ + j] = (__bf16)(v - (float)h);
       }
   }
   __syncthreads();
-  f32x4 o[2][NC];
+  f32x4 o[RT][NC];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int n = 0; n < NC; ++n) o[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ks = 0; ks < kNP / 32; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) fetch_d(ks + 1, dn);
     bf16x8 ahi[NC], alo[NC];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-      const int off = (16 * n + mi) * kPJ + 32 * ks + 8 * mh;
+      const int off = (16 * n + mi) * PJ + 32 * ks + 8 * mh;
       ahi[n] = *reinterpret_cast<const bf16x8 *>(hthi + off);
       alo[n] = *reinterpret_cast<const bf16x8 *>(htlo + off);
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       bf16x8 bhi, blo;
-      split8(dr[ks][rt][0], dr[ks][rt][1], bhi, blo);
+      split8(dr[rt][0], dr[rt][1], bhi, blo);
 #pragma unroll
       for (int n = 0; n < NC; ++n) o[rt][n] = mma3(ahi[n], alo[n], bhi, blo, o[rt][n]);
     }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      dr[rt][0] = dn[rt][0];
+      dr[rt][1] = dn[rt][1];
+    }
   }
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int row = (2 * wave + rt) * 16 + mi;
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = (RT * wave + rt) * 16 + mi;
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const int c = c0 + 16 * n + 4 * mh;
@@ -116,7 +126,7 @@ __device__ inline void aggregate_store(f32x4 (&d)[2][NC], const float *__restric
   }
 }
 
-template <int NC, bool SPLIT>
+template <int NP, int NC, bool SPLIT>
 __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
                                                const float *__restrict__ x,
                                                const float *__restrict__ W,
@@ -124,34 +134,35 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
                                                float *__restrict__ part, int N, int Fin, int Fout,
                                                int kchunk, int relu, int64_t mstride_x,
                                                int64_t mstride_o) {
-  __shared__ __attribute__((aligned(16))) __bf16 ht[SPLIT ? 8 : 2 * 16 * NC * kPJ];
+  constexpr int RT = NP / 64, PJ = NP + 8;
+  __shared__ __attribute__((aligned(16))) __bf16 ht[SPLIT ? 8 : 2 * 16 * NC * PJ];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
   const int c0 = blockIdx.x * 16 * NC, member = blockIdx.y;
   const int k0 = blockIdx.z * kchunk, k1 = k0 + kchunk < Fin ? k0 + kchunk : Fin;
-  const float *xp[2], *wp[NC];
+  const float *xp[RT], *wp[NC];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    int row = (2 * wave + rt) * 16 + mi;
+  for (int rt = 0; rt < RT; ++rt) {
+    int row = (RT * wave + rt) * 16 + mi;
     row = row < N ? row : N - 1;                  // padded rows repeat the last one (finite values)
     xp[rt] = x + member * mstride_x + (int64_t)row * Fin + 8 * mh;
   }
 #pragma unroll
   for (int n = 0; n < NC; ++n) wp[n] = W + (int64_t)(c0 + 16 * n + mi) * Fin + 8 * mh;
 
-  f32x4 d[2][NC];
+  f32x4 d[RT][NC];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int n = 0; n < NC; ++n) d[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   // KU k-steps are in flight at any time: slot u is re-requested (KU steps ahead) as soon as its
   // values have been split -- with one step ahead the 32-deep loop ran at one memory round trip per
   // step (27 us for 1024 -> 512 on 125 rows)
-  constexpr int KU = NC == 1 ? 4 : 2;
-  float4_t xr[KU][2][2], wr[KU][NC][2];
+  constexpr int KU = (NC == 1 && RT == 2) ? 4 : 2;
+  float4_t xr[KU][RT][2], wr[KU][NC][2];
   auto fetch = [&](int u, int k) {
     k = k < k1 ? k : k1 - 32;                       // unconditional load, clamped into the range
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       xr[u][rt][0] = *reinterpret_cast<const float4_t *>(xp[rt] + k);
       xr[u][rt][1] = *reinterpret_cast<const float4_t *>(xp[rt] + k + 4);
     }
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
   for (int k = k0; k < k1; k += 32 * KU) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      bf16x8 xhi[2], xlo[2], whi[NC], wlo[NC];
+      bf16x8 xhi[RT], xlo[RT], whi[NC], wlo[NC];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) split8(xr[u][rt][0], xr[u][rt][1], xhi[rt], xlo[rt]);
+      for (int rt = 0; rt < RT; ++rt) split8(xr[u][rt][0], xr[u][rt][1], xhi[rt], xlo[rt]);
 #pragma unroll
       for (int n = 0; n < NC; ++n) split8(wr[u][n][0], wr[u][n][1], whi[n], wlo[n]);
       fetch(u, k + 32 * (KU + u));
@@ -177,15 +188,15 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
 #pragma unroll
         for (int n = 0; n < NC; ++n)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) d[rt][n] = mma3(whi[n], wlo[n], xhi[rt], xlo[rt], d[rt][n]);
+          for (int rt = 0; rt < RT; ++rt) d[rt][n] = mma3(whi[n], wlo[n], xhi[rt], xlo[rt], d[rt][n]);
       }
     }
   }
   if constexpr (SPLIT) {
     float *pm = part + ((int64_t)blockIdx.z * gridDim.y + member) * N * Fout;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const int row = (2 * wave + rt) * 16 + mi;
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = (RT * wave + rt) * 16 + mi;
 #pragma unroll
       for (int n = 0; n < NC; ++n)
         if (row < N)
@@ -193,25 +204,26 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
               float4_t{d[rt][n][0], d[rt][n][1], d[rt][n][2], d[rt][n][3]};
     }
   } else {
-    aggregate_store<NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
-                        ht + 16 * NC * kPJ);
+    aggregate_store<NP, NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
+                        ht + 16 * NC * PJ);
   }
 }
 
 // adds the partial h tiles in split order, then the second contraction
-template <int NC>
+template <int NP, int NC>
 __global__ __launch_bounds__(256) void k_small_finish(const float *__restrict__ dense,
                                                       const float *__restrict__ part,
                                                       const float *__restrict__ bias,
                                                       float *__restrict__ out, int N, int Fout,
                                                       int nsplit, int relu, int64_t mstride_o) {
-  __shared__ __attribute__((aligned(16))) __bf16 ht[2 * 16 * NC * kPJ];
+  constexpr int RT = NP / 64, PJ = NP + 8;
+  __shared__ __attribute__((aligned(16))) __bf16 ht[2 * 16 * NC * PJ];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
   const int c0 = blockIdx.x * 16 * NC, member = blockIdx.y;
-  f32x4 d[2][NC];
+  f32x4 d[RT][NC];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    int row = (2 * wave + rt) * 16 + mi;
+  for (int rt = 0; rt < RT; ++rt) {
+    int row = (RT * wave + rt) * 16 + mi;
     row = row < N ? row : N - 1;
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
@@ -230,33 +242,35 @@ __global__ __launch_bounds__(256) void k_small_finish(const float *__restrict__ 
       d[rt][n] = f32x4{acc[0], acc[1], acc[2], acc[3]};
     }
   }
-  aggregate_store<NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
-                      ht + 16 * NC * kPJ);
+  aggregate_store<NP, NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
+                      ht + 16 * NC * PJ);
 }
 
-// dense[i][j] = sum of the stored weights of entries (i <- j), zero elsewhere; one thread per row adds
-// its entries in stored order (multi-edges accumulate deterministically)
+// dense[i][j] = sum of the stored weights of entries (i <- j), zero elsewhere (NP x NP); one thread per
+// row adds its entries in stored order (multi-edges accumulate deterministically)
 __global__ void k_dense(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                        const float *__restrict__ val, int N, float *__restrict__ dense) {
-  const int i = blockIdx.x, j = threadIdx.x;            // kNP blocks x kNP threads
-  __shared__ float row[kNP];
+                        const float *__restrict__ val, int N, int NP, float *__restrict__ dense) {
+  const int i = blockIdx.x, j = threadIdx.x;            // NP blocks x NP threads
+  __shared__ float row[kMaxNodes];
   row[j] = 0.0f;
   __syncthreads();
   if (j == 0 && i < N)
     for (int32_t s = rowptr[i]; s < rowptr[i + 1]; ++s) row[col[s]] += val[s];
   __syncthreads();
-  dense[i * kNP + j] = row[j];
+  dense[i * NP + j] = row[j];
 }
 
 struct Shape {
   int nc, nsplit, kchunk;
 };
 
-inline Shape shape_for(int64_t Fin, int64_t Fout) {
+inline Shape shape_for(int64_t N, int64_t Fin, int64_t Fout) {
   Shape s;
   // wide blocks (64 columns) re-read x a quarter as often: worth it when x is large (long K) or when
   // there are plenty of column blocks anyway
-  s.nc = (Fout % 64 == 0 && (Fin >= 4096 || Fout >= 4096)) ? 4 : 1;
+  // (with 4 row tiles per wave -- more than 128 nodes -- the registers allow 32 columns, not 64)
+  const int wide = pad_nodes(N) == 128 ? 4 : 2;
+  s.nc = (Fout % (16 * wide) == 0 && (Fin >= 4096 || Fout >= 4096)) ? wide : 1;
   const int64_t blocks = Fout / (16 * s.nc);
   // K is cut over blocks whenever the column blocks alone leave most CUs idle: a block then walks at
   // least 128 of K (4 k-steps) and the partial tiles are added by k_small_finish
@@ -274,21 +288,24 @@ inline Shape shape_for(int64_t Fin, int64_t Fout) {
 
 }  // namespace
 
+extern "C" int gwen_gcn_small_pad(int64_t N) { return N >= 1 && N <= kMaxNodes ? pad_nodes(N) : GWEN_EINVAL; }
+
 extern "C" int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout) {
-  return N >= 1 && N <= kNP && Fin >= 32 && Fin % 32 == 0 && Fout >= 16 && Fout % 16 == 0 ? 1 : 0;
+  return N >= 1 && N <= kMaxNodes && Fin >= 32 && Fin % 32 == 0 && Fout >= 16 && Fout % 16 == 0 ? 1 : 0;
 }
 
 extern "C" int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin,
                                                    int64_t Fout) {
   if (!gwen_gcn_small_supported(N, Fin, Fout) || members < 0) return 0;
-  const Shape s = shape_for(Fin, Fout);
+  const Shape s = shape_for(N, Fin, Fout);
   return s.nsplit > 1 ? (int64_t)s.nsplit * members * N * Fout : 0;
 }
 
 extern "C" int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                                   int64_t N, float *dense, gwen_stream_t stream_) {
-  if (N < 1 || N > kNP || !rowptr || !col || !val || !dense) return GWEN_EINVAL;
-  k_dense<<<kNP, kNP, 0, gwen_stream(stream_)>>>(rowptr, col, val, (int)N, dense);
+  if (N < 1 || N > kMaxNodes || !rowptr || !col || !val || !dense) return GWEN_EINVAL;
+  const int np = pad_nodes(N);
+  k_dense<<<np, np, 0, gwen_stream(stream_)>>>(rowptr, col, val, (int)N, np, dense);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -305,25 +322,27 @@ extern "C" int gwen_gcn_small_layer_f32(const float *dense, const float *x, cons
   for (const void *p : al)
     if (p && !gwen_aligned(p, 16)) return GWEN_EINVAL;
   if (mstride_x % 4 || mstride_o % 4) return GWEN_EINVAL;
-  const Shape s = shape_for(Fin, Fout);
+  const Shape s = shape_for(N, Fin, Fout);
   if (s.nsplit > 1 && (!workspace || workspace_floats < (int64_t)s.nsplit * members * N * Fout))
     return GWEN_ENOSPACE;
   hipStream_t st = gwen_stream(stream_);
   const dim3 grid((unsigned)(Fout / (16 * s.nc)), (unsigned)members, (unsigned)s.nsplit);
   const dim3 fgrid((unsigned)(Fout / 16), (unsigned)members);   // the finish always 16 columns a block
-#define GWEN_S(NCV)                                                                                  \
-  if (s.nc == NCV) {                                                                                 \
+#define GWEN_S(NPV, NCV)                                                                             \
+  if (pad_nodes(N) == NPV && s.nc == NCV) {                                                          \
     if (s.nsplit > 1) {                                                                              \
-      k_small<NCV, true><<<grid, 256, 0, st>>>(dense, x, W, bias, out, workspace, (int)N, (int)Fin,   \
-                                               (int)Fout, s.kchunk, relu, mstride_x, mstride_o);     \
-      k_small_finish<1><<<fgrid, 256, 0, st>>>(dense, workspace, bias, out, (int)N, (int)Fout,        \
-                                               s.nsplit, relu, mstride_o);                           \
+      k_small<NPV, NCV, true><<<grid, 256, 0, st>>>(dense, x, W, bias, out, workspace, (int)N,        \
+                                                    (int)Fin, (int)Fout, s.kchunk, relu, mstride_x,   \
+                                                    mstride_o);                                      \
+      k_small_finish<NPV, 1><<<fgrid, 256, 0, st>>>(dense, workspace, bias, out, (int)N, (int)Fout,   \
+                                                    s.nsplit, relu, mstride_o);                      \
     } else {                                                                                         \
-      k_small<NCV, false><<<grid, 256, 0, st>>>(dense, x, W, bias, out, nullptr, (int)N, (int)Fin,    \
-                                                (int)Fout, s.kchunk, relu, mstride_x, mstride_o);    \
+      k_small<NPV, NCV, false><<<grid, 256, 0, st>>>(dense, x, W, bias, out, nullptr, (int)N,         \
+                                                     (int)Fin, (int)Fout, s.kchunk, relu, mstride_x,  \
+                                                     mstride_o);                                     \
     }                                                                                                \
   }
-  GWEN_S(1) GWEN_S(4)
+  GWEN_S(128, 1) GWEN_S(128, 4) GWEN_S(256, 1) GWEN_S(256, 2)
 #undef GWEN_S
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;

@@ -68,12 +68,13 @@ class GraphCSR:
         return self._grouped
 
     def dense(self) -> Optional[Tensor]:
-        """The graph as a dense 128 x 128 fp32 matrix for K7 (square graphs of at most 128 nodes: the
+        """The graph as a dense padded fp32 matrix for K7 (square graphs of at most 256 nodes: the
         reference's member graphs); None for larger or bipartite graphs.  Built on first use."""
-        if self.num_src >= 0 or not 1 <= self.num_nodes <= 128:
+        if self.num_src >= 0 or not 1 <= self.num_nodes <= 256:
             return None
         if self._dense is None:
-            d = torch.empty(128 * 128, dtype=torch.float32, device=self.device)
+            np_ = int(_lib.lib().gwen_gcn_small_pad(self.num_nodes))
+            d = torch.empty(np_ * np_, dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 rc = _lib.lib().gwen_gcn_dense_f32(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val),
                                                    self.num_nodes, _ptr(d), _stream(self.device))

@@ -124,7 +124,7 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
 
 def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
                 relu: bool = False) -> Tensor:
-    """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 128 nodes (dense adjacency)."""
+    """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 256 nodes (dense adjacency)."""
     _require(x, "x")
     _require(weight, "weight")
     x, weight = x.contiguous(), weight.contiguous()
@@ -132,7 +132,7 @@ def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     n, fout = graph.num_nodes, weight.size(0)
     dense = graph.dense()
     if dense is None or not _lib.lib().gwen_gcn_small_supported(n, fin, fout):
-        raise ValueError("K7 needs a square graph of at most 128 nodes, Fin % 32 == 0, Fout % 16 == 0")
+        raise ValueError("K7 needs a square graph of at most 256 nodes, Fin % 32 == 0, Fout % 16 == 0")
     if n_src != n or weight.size(1) != fin:
         raise ValueError("shape mismatch between x, weight and the graph")
     if bias is not None:

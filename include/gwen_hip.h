@@ -165,7 +165,7 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
  *   then K3) when fin < fout.  Explicit orders are taken literally, layer by layer.
  * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4/K5 layers;
  *   g_col/g_val may be NULL when no layer resolves to K4/K5, g_rowptr NULL = uniform layout).
- * dense: the graph as a dense 128 x 128 matrix (gwen_gcn_dense_f32) or NULL; when given and every
+ * dense: the graph as a dense padded matrix (gwen_gcn_dense_f32) or NULL; when given and every
  *   layer is AUTO and gwen_gcn_small_supported(N, fin, fout), every layer is ONE K7 launch.
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
  * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
@@ -205,17 +205,18 @@ int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float 
                          int32_t max_launches, int32_t *n_launches);
 
 /* ---------------------------------------------------------------------------------------------
- * K7  a whole GCNConv layer on a SMALL graph (N <= 128) with wide features -- the reference's own
+ * K7  a whole GCNConv layer on a SMALL graph (N <= 256) with wide features -- the reference's own
  * shape: the complete graph over ~125-150 ensemble members (/root/reference/src/gwen/utils.py:175-176),
  * features = flattened fields, hidden 1024 (/root/reference/src/gwen/config.json:9,12).
- *   gwen_gcn_dense_f32: dense[i*128 + j] = sum of the stored weights of entries (i <- j) of a prepared
- *     square CSR (K1), zero elsewhere; dense: fp32 [128*128].
+ *   gwen_gcn_dense_f32: dense[i*NP + j] = sum of the stored weights of entries (i <- j) of a prepared
+ *     square CSR (K1), zero elsewhere; NP = gwen_gcn_small_pad(N) = 128 or 256; dense: fp32 [NP*NP].
  *   gwen_gcn_small_layer_f32: out[m] = act( dense (x[m] W^T) + bias ), x [members, N, Fin] contiguous
  *     rows (member stride mstride_x), W [Fout, Fin], out [members, N, Fout]; Fin % 32 == 0,
  *     Fout % 16 == 0 (gwen_gcn_small_supported).  3xbf16 contractions, fp32 accumulation; the
  *     aggregation is a dense contraction, so only the summation order differs from K2's.
  *     workspace: gwen_gcn_small_workspace_floats() fp32 elements (0 unless K is cut over blocks).
  * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_small_pad(int64_t N);
 int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout);
 int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin, int64_t Fout);
 int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,

@@ -1,4 +1,4 @@
-"""K7 (gwen_gcn_small_layer_f32, gwen_gcn_dense_f32): whole GCNConv layers on graphs of at most 128 nodes
+"""K7 (gwen_gcn_small_layer_f32, gwen_gcn_dense_f32): whole GCNConv layers on graphs of at most 256 nodes
 with wide features -- the reference's own shape (complete graph over ~125 members,
 /root/reference/src/gwen/utils.py:175-176; hidden 1024, config.json:12) -- against the CPU oracle."""
 import numpy as np
@@ -9,7 +9,15 @@ from helpers import REL_TOL, SEED, graph_cases, make_params, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-SMALL = [c for c in graph_cases() if c[1] <= 128]
+def _cases():
+    from gwen_amd.mesh import complete_graph
+    cases = [c for c in graph_cases() if c[1] <= 256]
+    cases.append(("K150", 150, torch.from_numpy(complete_graph(150))))      # the reference's upper range
+    cases.append(("K256", 256, torch.from_numpy(complete_graph(256))))
+    return cases
+
+
+SMALL = _cases()
 
 
 @pytest.fixture(scope="module")
@@ -22,9 +30,10 @@ def ga(hip_lib):
 def test_dense_matrix_is_the_normalised_adjacency(ga, name, n, ei):
     from oracle import gcn_oracle as O
     g = ga.prepare_graph(ei.to(DEV), n)
-    d = g.dense().cpu().view(128, 128)
+    npad = 128 if n <= 128 else 256
+    d = g.dense().cpu().view(npad, npad)
     ei2, w = O.gcn_norm(ei, None, n)
-    want = torch.zeros(128, 128, dtype=torch.float64)
+    want = torch.zeros(npad, npad, dtype=torch.float64)
     want.index_put_((ei2[1], ei2[0]), w.double(), accumulate=True)
     assert rel_err(d, want) <= 1e-6
     assert torch.count_nonzero(d[n:]) == 0 and torch.count_nonzero(d[:, n:]) == 0
@@ -51,11 +60,11 @@ def test_small_layer_vs_oracle(ga, name, n, ei, fin, fout, members, relu, use_bi
     assert torch.equal(got, again)
 
 
-def test_reference_shaped_model_runs_on_k7(ga):
+@pytest.mark.parametrize("n,c,h", [(125, 2048, 256), (150, 4096, 512)])
+def test_reference_shaped_model_runs_on_k7(ga, n, c, h):
     """GNNModel on the reference's graph family: every layer is one K7 launch, result within tolerance."""
     from gwen_amd.mesh import complete_graph
     from oracle import gcn_oracle as O
-    n, c, h = 125, 2048, 256
     ei = torch.from_numpy(complete_graph(n))
     torch.manual_seed(SEED)
     model = ga.GNNModel(ga.GNNConfig(n, n, c, c, h))
