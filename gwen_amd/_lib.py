@@ -25,7 +25,7 @@ _vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 class LayerDesc(C.Structure):
     """gwen_layer_desc (include/gwen_hip.h)."""
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("fin", C.c_int32), ("fout", C.c_int32),
-                ("relu", C.c_int32), ("order", C.c_int32)]
+                ("relu", C.c_int32), ("order", C.c_int32), ("packed", C.c_void_p)]
 
 
 class LaunchInfo(C.Structure):
@@ -79,7 +79,9 @@ SIGNATURES = {
     "gwen_gcn_small_supported": (_int, [_i64, _i64, _i64]),
     "gwen_gcn_small_workspace_floats": (_i64, [_i64, _i64, _i64, _i64]),
     "gwen_gcn_dense_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "gwen_gcn_small_layer_f32": (_int, [_vp] * 5 + [_i64] * 6 + [_int, _vp, _i64, _vp]),
+    "gwen_gcn_small_pack_bytes": (_i64, [_i64, _i64]),
+    "gwen_gcn_small_pack_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "gwen_gcn_small_layer_f32": (_int, [_vp] * 6 + [_i64] * 6 + [_int, _vp, _i64, _vp]),
     "gwen_mlp2_supported": (_int, [_i64]),
     "gwen_edge_tiles_count": (_i64, [_i64, _i64]),
     "gwen_edge_tiles": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),

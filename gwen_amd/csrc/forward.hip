@@ -116,7 +116,7 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
       const gwen_layer_desc &L = layers[i];
       float *dst = i + 1 == n_layers ? out : buf[i & 1];
       GWEN_TRY(before(GWEN_KIND_SMALL, i, L.fin, L.fout));
-      GWEN_TRY(gwen_gcn_small_layer_f32(dense, cur, L.W, L.bias, dst, N, L.fin, L.fout, members,
+      GWEN_TRY(gwen_gcn_small_layer_f32(dense, cur, L.W, L.packed, L.bias, dst, N, L.fin, L.fout, members,
                                         N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats, stream));
       GWEN_TRY(after());
       cur = dst;

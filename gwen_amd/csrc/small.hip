@@ -126,7 +126,7 @@ __device__ inline void aggregate_store(f32x4 (&d)[NP / 64][NC], const float *__r
   }
 }
 
-template <int NP, int NC, bool SPLIT>
+template <int NP, int NC, bool SPLIT, bool PACKED>
 __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
                                                const float *__restrict__ x,
                                                const float *__restrict__ W,
@@ -137,9 +137,22 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
   constexpr int RT = NP / 64, PJ = NP + 8;
   __shared__ __attribute__((aligned(16))) __bf16 ht[SPLIT ? 8 : 2 * 16 * NC * PJ];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
-  const int c0 = blockIdx.x * 16 * NC, member = blockIdx.y;
-  const int k0 = blockIdx.z * kchunk, k1 = k0 + kchunk < Fin ? k0 + kchunk : Fin;
+  int cb = blockIdx.x, sp = blockIdx.z;
+  if (SPLIT && gridDim.y == 1 && gridDim.z % 8 == 0) {
+    // the column blocks of one K range share one chunk of x: deal them to ONE XCD (linear block id
+    // % 8), whose L2 then serves that chunk after the first read (x does not fit an L2 as a whole)
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z, q = lin >> 3;
+    cb = q % gridDim.x;
+    sp = (q / gridDim.x) * 8 + (lin & 7);
+  }
+  const int c0 = cb * 16 * NC, member = blockIdx.y;
+  const int k0 = sp * kchunk, k1 = k0 + kchunk < Fin ? k0 + kchunk : Fin;
   const float *xp[RT], *wp[NC];
+  // PACKED: W points at the bf16 images of gwen_gcn_small_pack_f32 -- fragment (jt, ks) of lane l at
+  // ((jt KS + ks) 64 + l) x 16 bytes (hi image, then lo image): one contiguous KB per wave load, a
+  // contiguous stream per column tile, no split arithmetic
+  const bf16x8 *ip[NC];
+  const int64_t lo_off = (int64_t)Fout * Fin / 8;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     int row = (RT * wave + rt) * 16 + mi;
@@ -147,7 +160,10 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
     xp[rt] = x + member * mstride_x + (int64_t)row * Fin + 8 * mh;
   }
 #pragma unroll
-  for (int n = 0; n < NC; ++n) wp[n] = W + (int64_t)(c0 + 16 * n + mi) * Fin + 8 * mh;
+  for (int n = 0; n < NC; ++n) {
+    wp[n] = W + (int64_t)(c0 + 16 * n + mi) * Fin + 8 * mh;
+    ip[n] = reinterpret_cast<const bf16x8 *>(W) + (int64_t)(c0 / 16 + n) * (Fin / 32) * 64 + lane;
+  }
 
   f32x4 d[RT][NC];
 #pragma unroll
@@ -168,8 +184,13 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
     }
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-      wr[u][n][0] = *reinterpret_cast<const float4_t *>(wp[n] + k);
-      wr[u][n][1] = *reinterpret_cast<const float4_t *>(wp[n] + k + 4);
+      if constexpr (PACKED) {
+        wr[u][n][0] = *reinterpret_cast<const float4_t *>(ip[n] + (k >> 5) * 64);
+        wr[u][n][1] = *reinterpret_cast<const float4_t *>(ip[n] + (k >> 5) * 64 + lo_off);
+      } else {
+        wr[u][n][0] = *reinterpret_cast<const float4_t *>(wp[n] + k);
+        wr[u][n][1] = *reinterpret_cast<const float4_t *>(wp[n] + k + 4);
+      }
     }
   };
 #pragma unroll
@@ -182,7 +203,14 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) split8(xr[u][rt][0], xr[u][rt][1], xhi[rt], xlo[rt]);
 #pragma unroll
-      for (int n = 0; n < NC; ++n) split8(wr[u][n][0], wr[u][n][1], whi[n], wlo[n]);
+      for (int n = 0; n < NC; ++n) {
+        if constexpr (PACKED) {
+          whi[n] = __builtin_bit_cast(bf16x8, wr[u][n][0]);
+          wlo[n] = __builtin_bit_cast(bf16x8, wr[u][n][1]);
+        } else {
+          split8(wr[u][n][0], wr[u][n][1], whi[n], wlo[n]);
+        }
+      }
       fetch(u, k + 32 * (KU + u));
       if (k + 32 * u < k1) {                        // uniform: the range need not be a multiple of KU
 #pragma unroll
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
     }
   }
   if constexpr (SPLIT) {
-    float *pm = part + ((int64_t)blockIdx.z * gridDim.y + member) * N * Fout;
+    float *pm = part + ((int64_t)sp * gridDim.y + member) * N * Fout;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int row = (RT * wave + rt) * 16 + mi;
@@ -260,6 +288,18 @@ __global__ void k_dense(const int32_t *__restrict__ rowptr, const int32_t *__res
   dense[i * NP + j] = row[j];
 }
 
+// W [Fout, Fin] fp32 -> hi / lo bf16 images in fragment order; one wave per (column tile, k-step)
+__global__ __launch_bounds__(64) void k_pack_w(const float *__restrict__ W, int Fin, int64_t lo_off,
+                                               bf16x8 *__restrict__ img) {
+  const int lane = threadIdx.x, mi = lane & 15, mh = lane >> 4;
+  const int64_t frag = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;       // jt * KS + ks
+  const float *wp = W + ((int64_t)blockIdx.y * 16 + mi) * Fin + 32 * blockIdx.x + 8 * mh;
+  bf16x8 hi, lo;
+  split8(*reinterpret_cast<const float4_t *>(wp), *reinterpret_cast<const float4_t *>(wp + 4), hi, lo);
+  img[frag * 64 + lane] = hi;
+  img[lo_off + frag * 64 + lane] = lo;
+}
+
 struct Shape {
   int nc, nsplit, kchunk;
 };
@@ -310,15 +350,30 @@ extern "C" int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, con
   return GWEN_OK;
 }
 
+extern "C" int64_t gwen_gcn_small_pack_bytes(int64_t Fin, int64_t Fout) {
+  return Fin >= 32 && Fin % 32 == 0 && Fout >= 16 && Fout % 16 == 0 ? Fin * Fout * 4 : 0;
+}
+
+extern "C" int gwen_gcn_small_pack_f32(const float *W, int64_t Fin, int64_t Fout, void *packed,
+                                       gwen_stream_t stream_) {
+  if (!gwen_gcn_small_pack_bytes(Fin, Fout) || !W || !packed) return GWEN_EINVAL;
+  if (!gwen_aligned(W, 16) || !gwen_aligned(packed, 16) || Fout / 16 > 65535) return GWEN_EINVAL;
+  k_pack_w<<<dim3((unsigned)(Fin / 32), (unsigned)(Fout / 16)), 64, 0, gwen_stream(stream_)>>>(
+      W, (int)Fin, Fin * Fout / 8, reinterpret_cast<bf16x8 *>(packed));
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
 extern "C" int gwen_gcn_small_layer_f32(const float *dense, const float *x, const float *W,
+                                        const void *packed,
                                         const float *bias, float *out, int64_t N, int64_t Fin,
                                         int64_t Fout, int64_t members, int64_t mstride_x,
                                         int64_t mstride_o, int relu, float *workspace,
                                         int64_t workspace_floats, gwen_stream_t stream_) {
   if (members < 0 || !gwen_gcn_small_supported(N, Fin, Fout)) return GWEN_EINVAL;
   if (members == 0) return GWEN_OK;
-  if (!dense || !x || !W || !out || x == out || members > 65535) return GWEN_EINVAL;
-  const void *al[] = {dense, x, W, bias, out, workspace};
+  if (!dense || !x || (!W && !packed) || !out || x == out || members > 65535) return GWEN_EINVAL;
+  const void *al[] = {dense, x, W, packed, bias, out, workspace};
   for (const void *p : al)
     if (p && !gwen_aligned(p, 16)) return GWEN_EINVAL;
   if (mstride_x % 4 || mstride_o % 4) return GWEN_EINVAL;
@@ -328,22 +383,24 @@ extern "C" int gwen_gcn_small_layer_f32(const float *dense, const float *x, cons
   hipStream_t st = gwen_stream(stream_);
   const dim3 grid((unsigned)(Fout / (16 * s.nc)), (unsigned)members, (unsigned)s.nsplit);
   const dim3 fgrid((unsigned)(Fout / 16), (unsigned)members);   // the finish always 16 columns a block
+  const float *wsrc = packed ? reinterpret_cast<const float *>(packed) : W;
+#define GWEN_K(NPV, NCV, SP, PK)                                                                     \
+  k_small<NPV, NCV, SP, PK><<<grid, 256, 0, st>>>(dense, x, wsrc, bias, out, workspace, (int)N,       \
+                                                  (int)Fin, (int)Fout, s.kchunk, relu, mstride_x,     \
+                                                  mstride_o)
 #define GWEN_S(NPV, NCV)                                                                             \
   if (pad_nodes(N) == NPV && s.nc == NCV) {                                                          \
     if (s.nsplit > 1) {                                                                              \
-      k_small<NPV, NCV, true><<<grid, 256, 0, st>>>(dense, x, W, bias, out, workspace, (int)N,        \
-                                                    (int)Fin, (int)Fout, s.kchunk, relu, mstride_x,   \
-                                                    mstride_o);                                      \
+      if (packed) GWEN_K(NPV, NCV, true, true); else GWEN_K(NPV, NCV, true, false);                  \
       k_small_finish<NPV, 1><<<fgrid, 256, 0, st>>>(dense, workspace, bias, out, (int)N, (int)Fout,   \
                                                     s.nsplit, relu, mstride_o);                      \
     } else {                                                                                         \
-      k_small<NPV, NCV, false><<<grid, 256, 0, st>>>(dense, x, W, bias, out, nullptr, (int)N,         \
-                                                     (int)Fin, (int)Fout, s.kchunk, relu, mstride_x,  \
-                                                     mstride_o);                                     \
+      if (packed) GWEN_K(NPV, NCV, false, true); else GWEN_K(NPV, NCV, false, false);                \
     }                                                                                                \
   }
   GWEN_S(128, 1) GWEN_S(128, 4) GWEN_S(256, 1) GWEN_S(256, 2)
 #undef GWEN_S
+#undef GWEN_K
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }

@@ -89,10 +89,28 @@ def event_bracket_overhead(device, samples: int = 32) -> float:
     return 0.5 * vals[len(vals) // 2]
 
 
+def pack_weight(weight: Tensor) -> Optional[Tensor]:
+    """The 3xbf16 hi / lo images of ``weight`` [Fout, Fin] in MFMA fragment order (gwen_gcn_small_pack_f32)
+    for K7, or None when the shape has no packed form.  As many bytes as the weight itself."""
+    fout, fin = weight.shape
+    nbytes = int(_lib.lib().gwen_gcn_small_pack_bytes(fin, fout))
+    if nbytes == 0 or not weight.is_cuda or weight.dtype != torch.float32:
+        return None
+    w = weight.detach().contiguous()
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.lib().gwen_gcn_small_pack_f32(_ptr(w), fin, fout, _ptr(img), _stream(w.device))
+    _lib.check(rc, "gwen_gcn_small_pack_f32")
+    return img
+
+
 class StackForward:
     """A stack of GCN layers bound to one prepared graph: ``run(x)`` is one C call."""
 
-    def __init__(self, layers: Sequence[Tuple[Tensor, Optional[Tensor], bool, str]], graph: GraphCSR):
+    def __init__(self, layers: Sequence[Tuple[Tensor, Optional[Tensor], bool, str]], graph: GraphCSR,
+                 packed: Optional[Sequence[Optional[Tensor]]] = None):
+        """``packed``: per layer the ``pack_weight`` image of its weight (or None) -- K7 then streams the
+        weights in fragment order (small graphs; the caller owns the cache, see GNNModel)."""
         if not layers:
             raise ValueError("need at least one layer")
         self.graph = graph
@@ -108,6 +126,9 @@ class StackForward:
             d.W, d.bias = w.data_ptr(), (0 if b is None else b.data_ptr())
             d.fout, d.fin = w.size(0), w.size(1)
             d.relu, d.order = int(relu), _ORDERS[order]
+            img = None if packed is None else packed[i]
+            d.packed = 0 if img is None else img.data_ptr()
+            self._keep.append(img)
         self.fin, self.fout = self.desc[0].fin, self.desc[len(layers) - 1].fout
         self._scratch: Optional[Tensor] = None
         self._scratch_key = None

@@ -20,7 +20,7 @@ from dataclasses import dataclass
 import torch
 from torch import Tensor, nn
 
-from .forward import StackForward
+from .forward import StackForward, pack_weight
 from .gcn_conv import GCNConv
 from .graph import GraphCSR, default_cache
 
@@ -110,6 +110,28 @@ class GNNModel(nn.Module):
         super().__init__()
         self.conv_layers = GCNConvLayers(gnn_configs)
         self.activation = torch.nn.ReLU()
+        self._packed = {}        # layer index -> (weight identity/version, packed image) for K7
+
+    def __getstate__(self):      # derived data: keep the module picklable (mp.spawn, mlflow) and small
+        state = self.__dict__.copy()
+        state["_packed"] = {}
+        return state
+
+    def _packed_weights(self, graph: GraphCSR):
+        """Fragment-ordered weight images for K7 (small graphs, e.g. the reference's member graphs):
+        packed once per weight VERSION, so the eval loop re-uses them across batches and time steps
+        although every batch brings a new edge_index (models_gnn.py:351-360).  None on large graphs."""
+        if graph.dense() is None:
+            return None
+        out = []
+        for i, (w, _, _, order) in enumerate(self.stack()):
+            key = (w.data_ptr(), w._version, tuple(w.shape))
+            hit = self._packed.get(i)
+            if hit is None or hit[0] != key:
+                hit = (key, pack_weight(w) if order == "auto" else None)
+                self._packed[i] = hit
+            out.append(hit[1])
+        return out
 
     def prepare(self, edge_index: Tensor, num_nodes: int) -> GraphCSR:
         """Prepare (or fetch) the normalised graph all six layers share."""
@@ -131,4 +153,4 @@ class GNNModel(nn.Module):
         if needs_grad:
             return self.conv_layers(x, edge_index)          # per-layer autograd Functions
         # inference: the whole stack from one host call (gwen_gnn_forward_f32)
-        return StackForward(self.stack(), edge_index).run(x)
+        return StackForward(self.stack(), edge_index, self._packed_weights(edge_index)).run(x)

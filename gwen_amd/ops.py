@@ -123,8 +123,9 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
 
 
 def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-                relu: bool = False) -> Tensor:
-    """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 256 nodes (dense adjacency)."""
+                relu: bool = False, packed: Optional[Tensor] = None) -> Tensor:
+    """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 256 nodes (dense adjacency).
+    ``packed``: the weight's ``gwen_amd.forward.pack_weight`` image (streamed instead of ``weight``)."""
     _require(x, "x")
     _require(weight, "weight")
     x, weight = x.contiguous(), weight.contiguous()
@@ -143,7 +144,7 @@ def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     nws = int(_lib.lib().gwen_gcn_small_workspace_floats(n, m, fin, fout))
     ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws > 0 else None
     with torch.cuda.device(dev):
-        rc = _lib.lib().gwen_gcn_small_layer_f32(_ptr(dense), _ptr(x), _ptr(weight), _ptr(bias), _ptr(out),
+        rc = _lib.lib().gwen_gcn_small_layer_f32(_ptr(dense), _ptr(x), _ptr(weight), _ptr(packed), _ptr(bias), _ptr(out),
                                                  n, fin, fout, m, n * fin, n * fout, int(relu), _ptr(ws),
                                                  nws, _stream(dev))
     _lib.check(rc, "gwen_gcn_small_layer_f32")

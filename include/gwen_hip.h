@@ -188,6 +188,7 @@ typedef struct gwen_layer_desc {
   const float *W;
   const float *bias;
   int32_t fin, fout, relu, order;
+  const void *packed;  /* gwen_gcn_small_pack_f32 image of W for K7, or NULL */
 } gwen_layer_desc;
 
 typedef struct gwen_launch_info {
@@ -215,14 +216,22 @@ int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float 
  *     Fout % 16 == 0 (gwen_gcn_small_supported).  3xbf16 contractions, fp32 accumulation; the
  *     aggregation is a dense contraction, so only the summation order differs from K2's.
  *     workspace: gwen_gcn_small_workspace_floats() fp32 elements (0 unless K is cut over blocks).
+ *   gwen_gcn_small_pack_f32: W -> its 3xbf16 hi / lo images in MFMA fragment order
+ *     (gwen_gcn_small_pack_bytes() bytes, as many as W itself); pass the result as `packed` (W may then
+ *     be NULL) and the kernel streams the weights as one contiguous run per column tile -- worth it
+ *     when the weights are reused (inference): the C -> 1024 and 1024 -> C layers are bound by reading W.
  * ------------------------------------------------------------------------------------------- */
 int gwen_gcn_small_pad(int64_t N);
 int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout);
 int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin, int64_t Fout);
 int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
                        float *dense, gwen_stream_t stream);
-int gwen_gcn_small_layer_f32(const float *dense, const float *x, const float *W, const float *bias,
-                             float *out, int64_t N, int64_t Fin, int64_t Fout, int64_t members,
+int64_t gwen_gcn_small_pack_bytes(int64_t Fin, int64_t Fout);
+int gwen_gcn_small_pack_f32(const float *W, int64_t Fin, int64_t Fout, void *packed,
+                            gwen_stream_t stream);
+int gwen_gcn_small_layer_f32(const float *dense, const float *x, const float *W, const void *packed,
+                             const float *bias, float *out, int64_t N, int64_t Fin, int64_t Fout,
+                             int64_t members,
                              int64_t mstride_x, int64_t mstride_o, int relu, float *workspace,
                              int64_t workspace_floats, gwen_stream_t stream);
 

@@ -55,9 +55,11 @@ def test_small_layer_vs_oracle(ga, name, n, ei, fin, fout, members, relu, use_bi
     graph = ga.prepare_graph(ei.to(DEV), n)
     xs = x.to(DEV) if members > 1 else x[0].to(DEV)
     got = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu)
-    again = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu)
+    from gwen_amd.forward import pack_weight
+    img = pack_weight(w.to(DEV))                 # same hi/lo values, streamed in fragment order
+    again = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu, packed=img)
     assert rel_err(got.view(members, n, fout), want) <= 2e-5
-    assert torch.equal(got, again)
+    assert img.numel() == w.numel() * 4 and torch.equal(got, again)
 
 
 @pytest.mark.parametrize("n,c,h", [(125, 2048, 256), (150, 4096, 512)])

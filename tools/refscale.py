@@ -13,7 +13,7 @@ torch.manual_seed(23)
 model = gwen_amd.GNNModel(gwen_amd.GNNConfig(n, n, c, c, h)).to(dev).eval()
 x = torch.randn(n, c, device=dev)
 g = model.prepare(ei, n)
-plan = gwen_amd.StackForward(model.stack(), g)
+plan = gwen_amd.StackForward(model.stack(), g, model._packed_weights(g))
 ev = gwen_amd.KernelEvents(12)
 for _ in range(5):
     plan.run(x)
