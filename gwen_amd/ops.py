@@ -217,7 +217,8 @@ def relu_backward(y: Tensor, g: Tensor) -> Tensor:
 class GCNLayerFunction(torch.autograd.Function):
     """act(A~ (x W^T) + b): forward and backward entirely on the HIP kernels.
 
-    ``order``: "fused" = K4, one launch (chosen by "auto" whenever the widths allow); otherwise the
+    ``order``: "auto" picks "small" = K7 on graphs of at most 256 nodes (one launch, dense adjacency),
+    else "fused" = K4, one launch, whenever the widths allow; otherwise the
     two linear maps run as two launches, transform-first (x W^T, then aggregate at width Fout -- what
     PyG does) when Fout <= Fin, aggregate-first (A~ x at width Fin, then the projection with the
     bias/ReLU epilogue) when Fin < Fout, so the gather always runs at the narrower width.
@@ -229,11 +230,16 @@ class GCNLayerFunction(torch.autograd.Function):
                 relu: bool, order: str) -> Tensor:
         fout, fin = weight.shape
         if order == "auto":
-            if layer_supported(fin, fout):
+            if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout):
+                order = "small"              # K7: the reference's member graphs (<= 256 nodes)
+            elif layer_supported(fin, fout):
                 order = "fused"
             else:
                 order = "aggregate_first" if fin < fout else "transform_first"
-        if order in ("fused", "fused_exact"):
+        if order == "small":
+            out = small_layer(graph, x, weight, bias, relu)
+            saved_in = x
+        elif order in ("fused", "fused_exact"):
             out = layer_fused(graph, x, weight, bias, relu, exact=(order == "fused_exact"))
             saved_in = x
         elif order == "transform_first":
@@ -258,7 +264,7 @@ class GCNLayerFunction(torch.autograd.Function):
             g = relu_backward(out, g)
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         gx = gw = None
-        if ctx.order in ("transform_first", "fused", "fused_exact"):                # out = act(A~ x W^T + b) either way
+        if ctx.order in ("transform_first", "fused", "fused_exact", "small"):       # out = act(A~ x W^T + b) either way
             gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x

@@ -101,3 +101,29 @@ def test_small_layer_rejects_what_it_cannot_do(ga):
     g = ga.prepare_graph(torch.tensor([[0, 1], [1, 0]], device=DEV), 2)
     with pytest.raises(ValueError):
         ops.small_layer(g, torch.randn(2, 24, device=DEV), torch.randn(16, 24, device=DEV))
+
+
+def test_training_step_through_k7_matches_the_oracle(ga):
+    """One layer + ReLU on the reference's graph family: forward on K7, backward on K2^T / K3 / grad
+    kernels; gradients against the oracle's autograd in fp64."""
+    from gwen_amd.mesh import complete_graph
+    from oracle import gcn_oracle as O
+    n, fin, fout = 125, 64, 32
+    ei = torch.from_numpy(complete_graph(n))
+    torch.manual_seed(SEED)
+    conv = ga.GCNConv(fin, fout)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    ref = O.OracleGCNConv(fin, fout).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED))
+    xr = x.double().requires_grad_(True)
+    torch.relu(ref(xr, ei)).square().sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = conv(xg, ei.to(DEV), relu=True)
+    out.square().sum().backward()
+    assert rel_err(out.detach(), torch.relu(ref(xr, ei)).detach()) <= 2e-5
+    assert rel_err(xg.grad, xr.grad) <= REL_TOL
+    assert rel_err(conv.lin.weight.grad, ref.lin.weight.grad) <= REL_TOL
+    assert rel_err(conv.bias.grad, ref.bias.grad) <= REL_TOL
