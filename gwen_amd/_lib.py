@@ -85,7 +85,7 @@ SIGNATURES = {
     "gwen_mlp2_supported": (_int, [_i64]),
     "gwen_edge_tiles_count": (_i64, [_i64, _i64]),
     "gwen_edge_tiles": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "gwen_mlp2_f32": (_int, [_vp] * 4 + [_i64, _vp, _vp, _i64] + [_vp] * 5 + [_i64, _i64, _int, _vp, _vp, _i64,
+    "gwen_mlp2_f32": (_int, [_vp] * 4 + [_i64, _i64, _vp, _vp, _i64, _i64] + [_vp] * 5 + [_i64, _i64, _int, _vp, _vp, _i64,
                               _vp, _i64, _int, _vp, C.c_size_t, _vp]),
     "gwen_mlp2_workspace_bytes": (_i64, [_i64]),
     "gwen_mlp2_rows": (_int, [_i64]),

@@ -236,7 +236,8 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     const int32_t *__restrict__ idx2, const float *__restrict__ b1, const float *__restrict__ W2,
     const float *__restrict__ b2, const float *__restrict__ res, float *__restrict__ out,
     int32_t R, int act, const int32_t *__restrict__ rowptr,
-    const int32_t *__restrict__ tile_row, int32_t n_tiles, float *__restrict__ agg, int mean) {
+    const int32_t *__restrict__ tile_row, int32_t n_tiles, float *__restrict__ agg, int mean,
+    uint32_t ldb1, uint32_t ldb2) {                     // row strides of G1 / G2 in bytes
   using C = MCfg<F>;
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
   __bf16 *thi = reinterpret_cast<__bf16 *>(lds_raw);                    // A tile, hi / lo
@@ -333,10 +334,10 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
         add[k][n] = b1v[n];
         if constexpr (M1 != kNone)
           add[k][n] += *reinterpret_cast<const float4_t *>(
-              reinterpret_cast<const char *>(G1) + ((uint32_t)i1[k] * (F * 4u) + col(n) * 4u));
+              reinterpret_cast<const char *>(G1) + ((uint32_t)i1[k] * ldb1 + col(n) * 4u));
         if constexpr (M2 != kNone)
           add[k][n] += *reinterpret_cast<const float4_t *>(
-              reinterpret_cast<const char *>(G2) + ((uint32_t)i2[k] * (F * 4u) + col(n) * 4u));
+              reinterpret_cast<const char *>(G2) + ((uint32_t)i2[k] * ldb2 + col(n) * 4u));
       }
     // phase 4's row bounds for this thread's first target row, requested early
     int32_t seg_s = 0, seg_e = 0;
@@ -498,7 +499,8 @@ template <int F, int M1, int M2>
 int launch(const float *A, const float *W1, const float *G1, const int32_t *idx1, const float *G2,
            const int32_t *idx2, const float *b1, const float *W2, const float *b2, const float *res,
            float *out, int64_t R, int act, const int32_t *rowptr, const int32_t *tile_row,
-           int64_t n_tiles, float *agg, int mean, void *workspace, hipStream_t st) {
+           int64_t n_tiles, float *agg, int mean, void *workspace, uint32_t ldb1, uint32_t ldb2,
+           hipStream_t st) {
   using C = MCfg<F>;
   const bool seg = agg != nullptr;
   if constexpr (C::STREAM) {           // pre-split both matrices into fragment-ordered bf16 images
@@ -524,11 +526,11 @@ int launch(const float *A, const float *W1, const float *G1, const int32_t *idx1
   if (seg)
     k_mlp2<F, M1, M2, true><<<(unsigned)blocks, C::NWB * 64, 0, st>>>(
         A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, (int32_t)R, act, rowptr, tile_row,
-        (int32_t)tiles, agg, mean);
+        (int32_t)tiles, agg, mean, ldb1, ldb2);
   else
     k_mlp2<F, M1, M2, false><<<(unsigned)blocks, C::NWB * 64, 0, st>>>(
         A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, (int32_t)R, act, nullptr, nullptr,
-        (int32_t)tiles, nullptr, 0);
+        (int32_t)tiles, nullptr, 0, ldb1, ldb2);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -538,11 +540,11 @@ int launch_mode(int m1, int m2, const float *A, const float *W1, const float *G1
                 const float *G2, const int32_t *idx2, const float *b1, const float *W2,
                 const float *b2, const float *res, float *out, int64_t R, int act,
                 const int32_t *rowptr, const int32_t *tile_row, int64_t n_tiles, float *agg, int mean,
-                void *workspace, hipStream_t st) {
+                void *workspace, uint32_t ldb1, uint32_t ldb2, hipStream_t st) {
 #define GWEN_MODE(A1, A2)                                                                        \
   if (m1 == A1 && m2 == A2)                                                                      \
     return launch<F, A1, A2>(A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr,    \
-                             tile_row, n_tiles, agg, mean, workspace, st)
+                             tile_row, n_tiles, agg, mean, workspace, ldb1, ldb2, st)
   GWEN_MODE(kNone, kNone); GWEN_MODE(kSelf, kNone); GWEN_MODE(kIdx, kNone); GWEN_MODE(kIdx, kIdx);
 #undef GWEN_MODE
   return GWEN_EINVAL;
@@ -584,7 +586,8 @@ extern "C" int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int6
 }
 
 extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_t *idx1,
-                             int64_t G1_rows, const float *G2, const int32_t *idx2, int64_t G2_rows,
+                             int64_t G1_rows, int64_t ldg1, const float *G2, const int32_t *idx2,
+                             int64_t G2_rows, int64_t ldg2,
                              const float *b1, const float *W2, const float *b2, const float *res,
                              float *out, int64_t R, int64_t F, int act, const int32_t *rowptr,
                              const int32_t *tile_row, int64_t n_tiles, float *agg, int64_t N_agg,
@@ -605,7 +608,8 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
   // a table without an index is read row for row; the supported pairs are listed in the header
   const int m1 = !G1 ? kNone : (idx1 ? kIdx : kSelf), m2 = !G2 ? kNone : (idx2 ? kIdx : kSelf);
   if ((m1 == kSelf && G1_rows < R) || (m2 == kSelf && G2_rows < R)) return GWEN_EINVAL;
-  if ((G1 && G1_rows * F * 4 >= (int64_t(1) << 32)) || (G2 && G2_rows * F * 4 >= (int64_t(1) << 32)))
+  if ((G1 && (ldg1 < F || ldg1 % 4)) || (G2 && (ldg2 < F || ldg2 % 4))) return GWEN_EINVAL;
+  if ((G1 && G1_rows * ldg1 * 4 >= (int64_t(1) << 32)) || (G2 && G2_rows * ldg2 * 4 >= (int64_t(1) << 32)))
     return GWEN_ERANGE;              // 32-bit byte offsets into the tables
   if (out && (out == G1 || out == G2)) return GWEN_EINVAL;      // out may alias A / res row for row
   const int64_t need = gwen_mlp2_workspace_bytes(F);
@@ -616,7 +620,8 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
 #define GWEN_M(FF)                                                                                \
   if (F == FF)                                                                                    \
     return launch_mode<FF>(m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, \
-                           tile_row, n_tiles, agg, mean, workspace, st)
+                           tile_row, n_tiles, agg, mean, workspace, (uint32_t)(ldg1 * 4),       \
+                           (uint32_t)(ldg2 * 4), st)
   GWEN_M(32); GWEN_M(64); GWEN_M(128); GWEN_M(256);
 #undef GWEN_M
   return GWEN_EINVAL;

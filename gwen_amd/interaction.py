@@ -8,9 +8,10 @@ oracle/interaction_oracle.py, PARITY UNPINNED):
     agg_d = sum / mean of m_e over the in-edges of d
     x'_d  = x_dst_d + MLP_n([x_dst_d, agg_d]) ,   e' = e + m_e
 
-How it runs (5 launches, inference only):
-  * the node halves of both first layers are projected per NODE, not per edge (K3, 3xbf16):
-    Ps = x_src W1[:, F:2F]^T,  Pd = x_dst W1[:, 2F:]^T + b1,  Q = x_dst W3[:, :F]^T + b3;
+How it runs (3 launches on a square graph, 4 on a bipartite one; inference only):
+  * the node halves of both first layers are projected per NODE, not per edge, by ONE K3 launch with the
+    three weights stacked (3xbf16): [Ps | Pd | Q] = x [W1[:, F:2F]; W1[:, 2F:]; W3[:, :F]]^T + [0, b1, b3]
+    (sources projected apart when x_src is not x_dst); K6 reads them as strided column blocks;
   * K6 over edges (target-sorted):  e' and agg in one launch -- gathers Ps[s], Pd[d], never forms the
     [E,3F] concatenation, the hidden layer or the message tensor in HBM;
   * K6 over nodes:  x' = x_dst + act(agg W3[:, F:]^T + Q) W4^T + b4.
@@ -101,12 +102,19 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
         raise ValueError(f"K6 needs [rows, F] with F in (32, 64, 128, 256); got {tuple(a.shape)}")
     if tuple(w1.shape) != (f, f) or tuple(w2.shape) != (f, f):
         raise ValueError("W1 and W2 must be [F, F]")
-    ts = {"a": a, "w1": w1, "w2": w2, "b1": b1, "b2": b2, "g1": g1, "g2": g2, "res": res}
+    ts = {"a": a, "w1": w1, "w2": w2, "b1": b1, "b2": b2, "res": res}
     for name, t in ts.items():
         if t is not None:
             ops._require(t, name)
             ts[name] = t.contiguous()
-    a, w1, w2, b1, b2, g1, g2, res = (ts[k] for k in ("a", "w1", "w2", "b1", "b2", "g1", "g2", "res"))
+    a, w1, w2, b1, b2, res = (ts[k] for k in ("a", "w1", "w2", "b1", "b2", "res"))
+    # a table may be a column block of a wider row-major matrix (several projections from one launch)
+    for name, g in (("g1", g1), ("g2", g2)):
+        if g is not None:
+            ops._require(g, name)
+            if g.dim() != 2 or g.size(1) != f or g.stride(1) != 1 or g.stride(0) % 4 or g.stride(0) < f \
+                    or g.data_ptr() % 16:
+                raise ValueError(f"{name} must be [rows, F] with unit column stride and 16-byte aligned rows")
     rows = a.size(0)
     for name, idx, g in (("idx1", idx1, g1), ("idx2", idx2, g2)):
         if idx is not None and (g is None or idx.dtype != torch.int32 or idx.numel() != rows):
@@ -128,7 +136,8 @@ def mlp2(a: Tensor, w1: Tensor, w2: Tensor, b2: Optional[Tensor] = None, *,
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_mlp2_f32(
             _ptr(a), _ptr(w1), _ptr(g1), _ptr(idx1), 0 if g1 is None else g1.size(0),
-            _ptr(g2), _ptr(idx2), 0 if g2 is None else g2.size(0), _ptr(b1), _ptr(w2), _ptr(b2),
+            0 if g1 is None else g1.stride(0), _ptr(g2), _ptr(idx2), 0 if g2 is None else g2.size(0),
+            0 if g2 is None else g2.stride(0), _ptr(b1), _ptr(w2), _ptr(b2),
             _ptr(res), _ptr(out), rows, f, _ACT[act],
             _ptr(graph.rowptr) if graph else None, _ptr(tile_row), n_tiles, _ptr(agg),
             graph.num_dst if graph else 0, int(mean),
@@ -156,14 +165,19 @@ class InteractionNet(nn.Module):
         self._blocks = None          # contiguous [F,F] blocks of the two first layers + their versions
 
     def _weight_blocks(self):
-        """edge_mlp.0.weight = [We | Ws | Wd], node_mlp.0.weight = [Wx | Wa] as contiguous [F,F] blocks,
-        re-cut only when a parameter changed (in-place version counter) or moved."""
-        w1, w3, f = self.edge_mlp[0].weight, self.node_mlp[0].weight, self.channels
-        key = (w1._version, w3._version, w1.data_ptr(), w3.data_ptr())
+        """edge_mlp.0.weight = [We | Ws | Wd], node_mlp.0.weight = [Wx | Wa] re-cut for the kernels:
+        We, Wa contiguous [F,F]; the three NODE projections stacked as one [3F,F] weight (rows Ws, Wd,
+        Wx) with bias [0, b1, b3], so that one K3 launch serves all of them when x_src is x_dst (two
+        when not).  Re-cut only when a parameter changed (in-place version counter) or moved."""
+        l1, l3, f = self.edge_mlp[0], self.node_mlp[0], self.channels
+        key = tuple((p.data_ptr(), p._version) for p in (l1.weight, l1.bias, l3.weight, l3.bias))
         if self._blocks is None or self._blocks[0] != key:
             with torch.no_grad():
-                cut = tuple(w[:, i * f:(i + 1) * f].contiguous() for w, n in ((w1, 3), (w3, 2)) for i in range(n))
-            self._blocks = (key, cut)
+                w1, w3 = l1.weight, l3.weight
+                we, wa = w1[:, :f].contiguous(), w3[:, f:].contiguous()
+                wn = torch.cat([w1[:, f:2 * f], w1[:, 2 * f:], w3[:, :f]], dim=0).contiguous()
+                bn = torch.cat([torch.zeros_like(l1.bias), l1.bias, l3.bias]).contiguous()
+            self._blocks = (key, (we, wa, wn, bn))
         return self._blocks[1]
 
     def __getstate__(self):          # the cache is derived data: keep modules picklable and small
@@ -179,13 +193,17 @@ class InteractionNet(nn.Module):
         if x_src.shape != (graph.num_src, f) or x_dst.shape != (graph.num_dst, f) or \
                 e.shape != (graph.num_edges, f):
             raise ValueError("x_src / x_dst / e do not match the graph and the channel count")
-        we, ws, wd, wx, wa = self._weight_blocks()
-        ps = ops.linear(x_src, ws, None, exact=False)
-        pd = ops.linear(x_dst, wd, self.edge_mlp[0].bias, exact=False)
+        we, wa, wn, bn = self._weight_blocks()
+        if x_src is x_dst:                                   # mesh -> mesh: one launch, [N, 3F]
+            p = ops.linear(x_dst, wn, bn, exact=False)
+            ps, pd, q = p[:, :f], p[:, f:2 * f], p[:, 2 * f:]
+        else:                                                # bipartite: sources apart
+            ps = ops.linear(x_src, wn[:f], None, exact=False)
+            p = ops.linear(x_dst, wn[f:], bn[f:], exact=False)
+            pd, q = p[:, :f], p[:, f:]
         e_new, agg = mlp2(e, we, self.edge_mlp[2].weight, self.edge_mlp[2].bias,
                           g1=ps, idx1=graph.src, g2=pd, idx2=graph.dst, res=e, act=self.activation,
                           graph=graph, mean=self.aggr == "mean", want_out=update_edges)
-        q = ops.linear(x_dst, wx, self.node_mlp[0].bias, exact=False)
         x_new, _ = mlp2(agg, wa, self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
                         res=x_dst, act=self.activation)
         return x_new, e_new

@@ -273,7 +273,9 @@ int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t c
  *     out[r] = res[r] + y[r]                               (out, res optional; out may alias A / res)
  *     agg[d] = sum (or mean) of y[r] over rows r with rowptr[d] <= r < rowptr[d+1]   (agg optional)
  *   A, G*, res, out: fp32 row-major, contiguous rows of F; W1, W2: [F,F] row-major [out,in].
- *   G1 / G2 have G1_rows / G2_rows rows (rows * F * 4 < 2^32); supported table pairs: none; G1 alone
+ *   G1 / G2 have G1_rows / G2_rows rows with row stride ldg1 / ldg2 floats (>= F, multiple of 4;
+ *   rows * ld * 4 < 2^32 -- a table may be a column block of a wider matrix, e.g. one of several
+ *   projections computed by a single K3 launch); supported table pairs: none; G1 alone
  *   (with or without idx1); G1 and G2 both indexed.  GWEN_EINVAL otherwise.
  *   With agg: rows are the stored entries of a target-sorted CSR (rowptr int32 [N_agg+1],
  *   rowptr[N_agg] == R) and tile_row [n_tiles+1] comes from gwen_edge_tiles; every target row is
@@ -298,7 +300,8 @@ int64_t gwen_edge_tiles_count(int64_t E, int64_t T);
 int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int64_t T, int32_t *tile_row,
                     int32_t *dst, gwen_stream_t stream);
 int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_t *idx1,
-                  int64_t G1_rows, const float *G2, const int32_t *idx2, int64_t G2_rows,
+                  int64_t G1_rows, int64_t ldg1, const float *G2, const int32_t *idx2,
+                  int64_t G2_rows, int64_t ldg2,
                   const float *b1, const float *W2, const float *b2, const float *res, float *out,
                   int64_t R, int64_t F, int act, const int32_t *rowptr, const int32_t *tile_row,
                   int64_t n_tiles, float *agg, int64_t N_agg, int mean, void *workspace,

@@ -120,12 +120,16 @@ def test_interaction_block_vs_oracle(ga, name, F, act, aggr):
     want_x, want_e = IO.interaction(xs.double(), xd.double(), e.double(), ei, sd, act, aggr)
     graph = interaction_graph(ei.to(DEV), ns, nd)
     net = net.to(DEV)
+    xs_d = xs.to(DEV)
+    xd_d = xs_d if xd is xs else xd.to(DEV)      # same object: one stacked projection launch
     with torch.no_grad():
-        got_x, got_e = net(xs.to(DEV), xd.to(DEV), graph.sort_edges(e.to(DEV)), graph)
-        again_x, again_e = net(xs.to(DEV), xd.to(DEV), graph.sort_edges(e.to(DEV)), graph)
+        got_x, got_e = net(xs_d, xd_d, graph.sort_edges(e.to(DEV)), graph)
+        again_x, again_e = net(xs_d, xd_d, graph.sort_edges(e.to(DEV)), graph)
+        apart_x, apart_e = net(xs_d, xd_d.clone(), graph.sort_edges(e.to(DEV)), graph)   # sources apart
     assert rel_err(got_x, want_x) <= REL_TOL
     assert rel_err(graph.unsort_edges(got_e), want_e) <= REL_TOL
     assert torch.equal(got_x, again_x) and torch.equal(got_e, again_e)        # no atomics anywhere
+    assert rel_err(apart_x, want_x) <= REL_TOL and rel_err(graph.unsort_edges(apart_e), want_e) <= REL_TOL
 
 
 def test_closed_forms(ga):
@@ -164,6 +168,12 @@ def test_rejects_misuse(ga):
         mlp2(a, torch.randn(48, 48, device=DEV), torch.randn(48, 48, device=DEV))
     a = torch.randn(10, 64, device=DEV)
     w = torch.randn(64, 64, device=DEV)
+    wide = torch.randn(10, 192, device=DEV)
+    out_a, _ = mlp2(a, w, w, g1=wide[:, 64:128])                 # a column block of a wider matrix
+    out_b, _ = mlp2(a, w, w, g1=wide[:, 64:128].contiguous())
+    assert torch.equal(out_a, out_b)
+    with pytest.raises(ValueError):
+        mlp2(a, w, w, g1=wide[:, 2:66])                          # rows not 16-byte aligned
     with pytest.raises(ValueError):
         mlp2(a, w, w, g1=torch.randn(5, 64, device=DEV))
     with pytest.raises(ValueError):
