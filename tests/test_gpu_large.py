@@ -75,3 +75,30 @@ def test_sixteen_members_share_one_graph(ga):
         batched = model(x, ei)
         one = model(x[5], ei)
     assert torch.equal(batched[5], one)
+
+
+def test_interaction_block_at_full_mesh_size(ga):
+    """K6 at BASELINE's mesh size (nu = 100: 100 002 nodes, 600 000 edges) through size-independent
+    properties: zero second layers leave the state untouched; the aggregate equals the target-wise sum
+    of the edge updates (checked against torch's index_add_ on the device); two runs are bitwise equal."""
+    from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
+    F = 64
+    m = ga.geodesic_mesh(100, reorder="morton")
+    g = interaction_graph(torch.from_numpy(m.edge_index).to(DEV), m.num_nodes, m.num_nodes)
+    assert g.num_edges == 600000 and g.max_degree == 6
+    torch.manual_seed(SEED)
+    net = InteractionNet(F).to(DEV)
+    x = torch.randn(m.num_nodes, F, device=DEV)
+    e = torch.randn(g.num_edges, F, device=DEV)
+    with torch.no_grad():
+        x1, e1 = net(x, x, e, g)
+        x2, e2 = net(x, x, e, g)
+        assert torch.equal(x1, x2) and torch.equal(e1, e2)
+        w1 = net.edge_mlp[0].weight
+        out, agg = mlp2(e, w1[:, :F].contiguous(), net.edge_mlp[2].weight, net.edge_mlp[2].bias, graph=g)
+        want = torch.zeros(m.num_nodes, F, dtype=torch.float64, device=DEV).index_add_(0, g.dst.long(), out.double())
+        assert float((agg.double() - want).abs().max() / want.abs().max()) <= 1e-6
+        for p in (net.edge_mlp[2].weight, net.edge_mlp[2].bias, net.node_mlp[2].weight, net.node_mlp[2].bias):
+            p.zero_()
+        x3, e3 = net(x, x, e, g)
+    assert torch.equal(x3, x) and torch.equal(e3, e)

@@ -14,6 +14,9 @@ def _cases():
     cases = [c for c in graph_cases() if c[1] <= 256]
     cases.append(("K150", 150, torch.from_numpy(complete_graph(150))))      # the reference's upper range
     cases.append(("K256", 256, torch.from_numpy(complete_graph(256))))
+    from helpers import random_multigraph
+    cases.append(("multi100", 100, random_multigraph(100, 700, self_loops=15, dup=60, isolate=5)))
+    cases.append(("multi250", 250, random_multigraph(250, 3000, seed=7, self_loops=30, dup=200, isolate=9)))
     return cases
 
 
@@ -127,3 +130,22 @@ def test_training_step_through_k7_matches_the_oracle(ga):
     assert rel_err(xg.grad, xr.grad) <= REL_TOL
     assert rel_err(conv.lin.weight.grad, ref.lin.weight.grad) <= REL_TOL
     assert rel_err(conv.bias.grad, ref.bias.grad) <= REL_TOL
+
+
+def test_weighted_small_graph(ga):
+    """Explicit edge weights (and improved=True, which only acts on weighted graphs) reach K7 through
+    the dense matrix."""
+    from gwen_amd import ops
+    from helpers import random_multigraph
+    from oracle import gcn_oracle as O
+    n, fin, fout = 90, 64, 48
+    ei = random_multigraph(n, 500, seed=3, self_loops=10, dup=40)
+    gen = torch.Generator().manual_seed(SEED)
+    ew = torch.rand(ei.size(1), generator=gen) + 0.1
+    w, b = make_params(fin, fout)
+    x = torch.randn(n, fin, generator=gen)
+    for improved in (False, True):
+        want = O.gcn_conv(x.double(), ei, w.double(), b.double(), ew.double(), improved=improved)
+        g = ga.prepare_graph(ei.to(DEV), n, ew.to(DEV), improved=improved)
+        got = ops.small_layer(g, x.to(DEV), w.to(DEV), b.to(DEV))
+        assert rel_err(got, want) <= 2e-5
