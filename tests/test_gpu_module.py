@@ -115,3 +115,18 @@ def test_reference_scale_workload(ga):
     assert rel_err(got, want) <= REL_TOL
     # on K_N every output row is the same vector
     assert rel_err(got, got[0:1].expand_as(got)) <= 1e-5
+
+
+@pytest.mark.parametrize("F,steps", [(256, 4), (64, 3)])
+def test_c3_processor_stack_vs_oracle(F, steps):
+    """BASELINE config c3: chained F -> F GCN layers with ReLU on one mesh (oracle.processor_stack)."""
+    import gwen_amd
+    from oracle import gcn_oracle as O
+    mesh = gwen_amd.geodesic_mesh(10)
+    ei = torch.from_numpy(mesh.edge_index)
+    ws, bs = zip(*[make_params(F, F, seed=SEED + k) for k in range(steps)])
+    x = torch.randn(mesh.num_nodes, F, generator=torch.Generator().manual_seed(SEED))
+    want = O.processor_stack(x.double(), ei, [w.double() for w in ws], [b.double() for b in bs])
+    g = gwen_amd.prepare_graph(ei.to(DEV), mesh.num_nodes)
+    plan = gwen_amd.StackForward([(w.to(DEV), b.to(DEV), True, "auto") for w, b in zip(ws, bs)], g)
+    assert rel_err(plan.run(x.to(DEV)), want) <= REL_TOL
