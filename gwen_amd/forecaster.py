@@ -98,12 +98,44 @@ class InteractionForecaster(nn.Module):
             raise RuntimeError("InteractionForecaster is inference-only: call it under torch.no_grad()")
         return self._step(grid_x, graphs, self._static(graphs))
 
-    def rollout(self, grid_x: Tensor, graphs: ForecastGraphs, n_steps: int) -> List[Tensor]:
-        """Autoregressive: state_{t+1} = forward(state_t); returns the n_steps states."""
+    def rollout(self, grid_x: Tensor, graphs: ForecastGraphs, n_steps: int,
+                graphed: bool = False) -> List[Tensor]:
+        """Autoregressive: state_{t+1} = forward(state_t); returns the n_steps states.
+        ``graphed``: capture ONE step (its ~26 launches) into a hipGraph and replay it per step -- the
+        launchers allocate and synchronise nothing, so the step is capturable as is; worth it when the
+        host cannot keep ahead of the device (64 channels: 1.31 -> 1.14 ms per step; 128: 2.71 -> 2.39)."""
         states, cur = [], grid_x
         with torch.no_grad():
+            if graphed:
+                step = GraphedStep(self, graphs, grid_x)
+                for _ in range(n_steps):
+                    cur = step(cur).clone()
+                    states.append(cur)
+                return states
             static = self._static(graphs)
             for _ in range(n_steps):
                 cur = self._step(cur, graphs, static)
                 states.append(cur)
         return states
+
+
+class GraphedStep:
+    """One forecaster step captured into a hipGraph (``torch.cuda.CUDAGraph``): ``step(x)`` copies ``x``
+    into the static input, replays, and returns the static output (clone it to keep it)."""
+
+    def __init__(self, model: InteractionForecaster, graphs: ForecastGraphs, grid_x: Tensor):
+        self.x = grid_x.detach().clone()
+        self.graphs = graphs                                 # the graph holds raw pointers into these:
+        with torch.no_grad():                                # keep every tensor it reads alive
+            static = self._static = model._static(graphs)
+            model._step(self.x, graphs, static)             # warm-up: occupancy queries, tilings, caches
+            torch.cuda.synchronize(self.x.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.y = model._step(self.x, graphs, static)
+
+    def __call__(self, x: Tensor) -> Tensor:
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x)
+        self.graph.replay()
+        return self.y

@@ -220,3 +220,5 @@ def test_forecaster_and_rollout_vs_oracle(ga, C, H, steps, nsteps):
     assert torch.equal(one, got[0])
     for g_, w_ in zip(got, want):
         assert rel_err(g_, w_) <= REL_TOL
+    replayed = model.rollout(x0.to(DEV), graphs, nsteps, graphed=True)      # one captured step, replayed
+    assert all(torch.equal(a, b) for a, b in zip(replayed, got))

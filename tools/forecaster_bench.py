@@ -27,8 +27,18 @@ with torch.no_grad():
     model.rollout(x, graphs, 4)
     torch.cuda.synchronize()
     dr = time.perf_counter() - t0
+    from gwen_amd.forecaster import GraphedStep
+    gs = GraphedStep(model, graphs, x)
+    for _ in range(3):
+        gs(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        gs(x)
+    torch.cuda.synchronize()
+    dg = (time.perf_counter() - t0) / 10
 edges = graphs.g2m.num_edges + S * graphs.mesh.num_edges + graphs.m2g.num_edges
 print(json.dumps({"workload": f"InteractionNet forecaster nu=100 grid={mesh.faces.shape[0]} mesh={mesh.num_nodes} "
-                              f"C={C} H={H} processor_blocks={S}", "forward_us": round(dt * 1e6, 1),
+                              f"C={C} H={H} processor_blocks={S}", "forward_us": round(dt * 1e6, 1), "graphed_forward_us": round(dg * 1e6, 1),
                   "edge_updates_per_s": round(edges / dt), "rollout4_ms": round(dr * 1e3, 3),
                   "members_per_s_4step": round(1.0 / dr, 2)}))
