@@ -11,15 +11,18 @@
 // agg = sum of messages; with rows = nodes, A = agg, G1 = x W^T it is  x' = x + MLP_n([x, agg]).
 // Neither the [E,3F] concatenation, nor the hidden layer, nor the message tensor reaches HBM.
 //
-// Shape (wave64): a block = one TILE of at most 64 rows and NWB = F/16 waves (at least 4);
-//   wave j owns output columns 16 j .. 16 j + 15 of BOTH contractions and keeps its slices of W1 and
-//   W2 in registers as 3xbf16 fragments (hi/lo, see layer.hip), W as the MFMA A operand so a lane
-//   ends up with 4 consecutive columns of one row (16-B gathers, 16-B stores);
-//   phase 1  A rows (contiguous, coalesced 16-B loads) -> hi/lo bf16 LDS tiles;
-//   phase 2  pre = MFMA + gathered addends + b1, activation, back into the SAME LDS tiles (hi/lo);
+// Shape (wave64): a block = 8 waves that walk tiles of at most 64 rows persistently (one resident set
+//   of blocks; the tiles of one XCD are one contiguous eighth of them);
+//   a wave owns NC column tiles (16 NC output columns) of BOTH contractions and keeps its slices of W1
+//   and W2 in registers as 3xbf16 fragments (hi/lo, see layer.hip) -- at 256 channels they are streamed
+//   from pre-split images instead -- with W as the MFMA A operand, so a lane ends up with 4 consecutive
+//   columns of one row (16-B gathers, 16-B stores);
+//   phase 1  A rows, prefetched during the previous pass in the OUTPUT layout (the residual stays in
+//            registers) -> hi/lo bf16 LDS tile;
+//   phase 2  pre = MFMA + gathered addends + b1, activation -> hi/lo hidden tile (its own LDS image);
 //   phase 3  y = MFMA + b2; out = res + y stored from registers;
-//   phase 4  (aggregation) y -> LDS fp32 tile; one thread per (target row, 4 columns) adds its rows'
-//            entries in stored order -- no atomics, bitwise reproducible.
+//   phase 4  (aggregation) y -> LDS fp32 tile (aliases the A tile); one thread per (target row, 4
+//            columns) adds its rows' entries in stored order -- no atomics, bitwise reproducible.
 // Tiles are ROW-ALIGNED (gwen_edge_tiles): tile c owns the target rows whose first edge lies in
 //   [cT, (c+1)T), so every target row is summed by exactly one block; T = 64 - (max degree - 1) makes a
 //   tile one pass of 64 edges on bounded-degree graphs, and a row longer than a pass is carried

@@ -1,4 +1,4 @@
-// K7 -- one whole GCNConv layer on a SMALL graph (N <= 128 nodes) with WIDE features, the shape of the
+// K7 -- one whole GCNConv layer on a SMALL graph (N <= 256 nodes) with WIDE features, the shape of the
 // reference's own workload: its graph is the complete graph over ~125-150 ensemble members
 // (/root/reference/src/gwen/utils.py:175-176) and its features are flattened fields, C = height x
 // ncells -> hidden 1024 (/root/reference/src/gwen/config.json:9,12; layers
@@ -6,15 +6,17 @@
 // a 125-row projection is 2-8 blocks of the 128 x 128 tile kernel (18-30 us each) and every propagate
 // walks 125-entry rows 8 entries per memory round trip (14-17 us each): 272 us per forward.
 //
-// Here the normalised adjacency is a dense 128 x 128 matrix D (zero padded, built once per graph by
-// gwen_gcn_dense_f32) and a layer is two chained contractions per block of output columns,
+// Here the normalised adjacency is a dense NP x NP matrix D (NP = 128 or 256, zero padded, built once
+// per graph by gwen_gcn_dense_f32) and a layer is two chained contractions per block of output columns,
 //        h[:, cols] = x W[cols, :]^T          (K = Fin, streamed from global memory, no LDS)
-//        out[:, cols] = act( D h[:, cols] + b[cols] )      (K = 128, h through LDS, transposed)
+//        out[:, cols] = act( D h[:, cols] + b[cols] )      (K = NP, h through LDS, transposed)
 // both as 3xbf16 split MFMAs with fp32 accumulation (see layer.hip).  Only the summation ORDER differs
 // from the sequential edge-order sum of K2 (fp32 rounding; parity tolerance 1e-4 as everywhere).
-//   block = 4 waves = all 128 (padded) rows x BN = 16 NC output columns; wave w owns row tiles 2w, 2w+1;
+//   block = 4 waves = all NP (padded) rows x BN = 16 NC output columns; wave w owns NP/64 row tiles;
 //   W is the MFMA A operand, x the B operand, both read straight from global memory in fragment layout
-//   (8 consecutive floats per lane = 32 B, 128 B contiguous per row per k-step) one k-step ahead;
+//   (8 consecutive floats per lane = 32 B, 128 B contiguous per row per k-step), 2-4 k-steps in flight;
+//   weights that are re-used come pre-split in fragment order (gwen_gcn_small_pack_f32): one contiguous
+//   KB per wave load;
 //   a long K (the C -> 1024 projection) is cut over blockIdx.z: partial h tiles go to a workspace and
 //   k_small_finish adds them in split order before the second contraction.
 #include "common.h"
