@@ -119,6 +119,26 @@ class InteractionForecaster(nn.Module):
         return states
 
 
+def ensemble_forecast(model: InteractionForecaster, graphs: ForecastGraphs, x_members: Tensor,
+                      n_steps: int, num_members: int, group=None, graphed: bool = True) -> Tensor:
+    """BASELINE config c5: this rank's members ``[members_local, N_grid, C]`` are rolled out ``n_steps``
+    steps each (independent members, replicated graph and weights, one captured step replayed for all
+    of them), then every rank's final states are gathered ONCE (``ensemble.gather_members``: RCCL
+    all-gather over xGMI under the "nccl" backend).  Returns ``[num_members, N_grid, C]`` on every rank."""
+    from . import ensemble
+    finals = []
+    with torch.no_grad():
+        step = GraphedStep(model, graphs, x_members[0]) if graphed and x_members.size(0) > 0 else None
+        static = None if step is not None else model._static(graphs)
+        for m in range(x_members.size(0)):
+            cur = x_members[m]
+            for _ in range(n_steps):
+                cur = step(cur).clone() if step is not None else model._step(cur, graphs, static)
+            finals.append(cur)
+    local = torch.stack(finals) if finals else x_members.new_empty((0,) + tuple(x_members.shape[1:]))
+    return ensemble.gather_members(local, num_members, group)
+
+
 class GraphedStep:
     """One forecaster step captured into a hipGraph (``torch.cuda.CUDAGraph``): ``step(x)`` copies ``x``
     into the static input, replays, and returns the static output (clone it to keep it)."""

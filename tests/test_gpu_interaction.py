@@ -222,3 +222,19 @@ def test_forecaster_and_rollout_vs_oracle(ga, C, H, steps, nsteps):
         assert rel_err(g_, w_) <= REL_TOL
     replayed = model.rollout(x0.to(DEV), graphs, nsteps, graphed=True)      # one captured step, replayed
     assert all(torch.equal(a, b) for a, b in zip(replayed, got))
+
+
+def test_ensemble_forecast_single_rank(ga):
+    """c5 shape on one rank: every member rolled out independently, gathered once (no process group:
+    the gather is the identity); graphed and eager paths agree bitwise."""
+    from gwen_amd.forecaster import InteractionForecaster, ensemble_forecast
+    m = ga.geodesic_mesh(4)
+    torch.manual_seed(SEED)
+    model = InteractionForecaster(8, 32, 2).to(DEV).eval()
+    graphs = model.prepare(m, DEV)
+    xm = torch.randn(3, m.faces.shape[0], 8, device=DEV)
+    a = ensemble_forecast(model, graphs, xm, 2, 3, graphed=True)
+    b = ensemble_forecast(model, graphs, xm, 2, 3, graphed=False)
+    assert a.shape == (3, m.faces.shape[0], 8) and torch.equal(a, b)
+    want = torch.stack([model.rollout(xm[i], graphs, 2)[-1] for i in range(3)])
+    assert torch.equal(a, want)
