@@ -9,11 +9,15 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kChunkRows = 1024;   // rows reduced by one block before the cross-chunk stage
+constexpr int kChunkRows = 256;    // rows reduced by one block before the cross-chunk stage
+constexpr int kU = 8;              // independent loads in flight per thread in every reduction loop
 
 // One wave = one 32x32 tile of grad_W (rows = output channel, cols = input channel) over one chunk
 // of node rows.  A[i = l&31][k = l>>5] = g[row k][o0 + i], B[k][j = l&31] = x[row k][i0 + j]:
 // both operands are 128-B contiguous global reads per half-wave, so no LDS staging is needed.
+// Every load is unconditional (clamped row / column, value masked afterwards) and kU row pairs are
+// requested before the first MFMA: with one dependent load pair per MFMA and 1024-row chunks this
+// kernel ran at one memory round trip per two rows (206 us for 64 x 64 on 100 002 rows).
 __global__ __launch_bounds__(kThreads) void k_grad_w(const float *__restrict__ g,
                                                      const float *__restrict__ x,
                                                      float *__restrict__ dst, int64_t rows, int Fin,
@@ -27,13 +31,22 @@ __global__ __launch_bounds__(kThreads) void k_grad_w(const float *__restrict__ g
   const int64_t r0 = (int64_t)blockIdx.x * kChunkRows;
   const int64_t r1 = (r0 + kChunkRows < rows) ? r0 + kChunkRows : rows;
   const bool ao = o0 + li < Fout, ai = i0 + li < Fin;
-  const float *gp = g + o0 + li, *xp = x + i0 + li;
+  const float *gp = g + (ao ? o0 + li : Fout - 1), *xp = x + (ai ? i0 + li : Fin - 1);
   f32x16 acc = {};
-  for (int64_t r = r0 + lh; r < r1 + lh; r += 2) {     // every lane runs the same trip count
-    const bool in = r < r1;
-    const float a = (in && ao) ? gp[r * ldg] : 0.0f;
-    const float b = (in && ai) ? xp[r * ldx] : 0.0f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  for (int64_t r = r0 + lh; r < r1 + lh; r += 2 * kU) {     // every lane runs the same trip count
+    float a[kU], b[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t rr = r + 2 * u, rc = rr < r1 ? rr : r1 - 1;
+      a[u] = gp[rc * ldg];
+      b[u] = xp[rc * ldx];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const bool in = r + 2 * u < r1;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32((in && ao) ? a[u] : 0.0f, (in && ai) ? b[u] : 0.0f,
+                                                 acc, 0, 0, 0);
+    }
   }
   float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
   if (!ai) return;
@@ -44,27 +57,58 @@ __global__ __launch_bounds__(kThreads) void k_grad_w(const float *__restrict__ g
   }
 }
 
-// dst[j] = sum over chunks c (ascending) of partial[c][j]
-__global__ void k_reduce_chunks(const float *__restrict__ partial, float *__restrict__ dst,
-                                int64_t count, int nchunks) {
-  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (j >= count) return;
+// dst[j] = sum over chunks of partial[c][j], in a fixed order: 16 phases (phase p adds chunks p, p+16,
+// ... ascending, kU loads in flight), folded through LDS in phase order.  Block = 16 elements x 16 phases.
+__global__ __launch_bounds__(kThreads) void k_reduce_chunks(const float *__restrict__ partial,
+                                                            float *__restrict__ dst, int64_t count,
+                                                            int nchunks) {
+  __shared__ float red[kThreads];
+  const int e = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int64_t j = (int64_t)blockIdx.x * 16 + e, jc = j < count ? j : count - 1;
   float s = 0.0f;
-  for (int c = 0; c < nchunks; ++c) s = s + partial[(int64_t)c * count + j];
-  dst[j] = s;
+  for (int c = ph; c < nchunks; c += 16 * kU) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int cc = c + 16 * u < nchunks ? c + 16 * u : nchunks - 1;
+      v[u] = partial[(int64_t)cc * count + jc];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (c + 16 * u < nchunks) s = s + v[u];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ph == 0 && j < count) {
+    float tot = red[e];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) tot = tot + red[16 * p + e];
+    dst[j] = tot;
+  }
 }
 
-// column sums of one chunk of rows: thread = column, 4 row phases per block folded through LDS
+// column sums of one chunk of rows: thread = column, 4 row phases per block folded through LDS,
+// kU loads in flight per thread
 __global__ __launch_bounds__(kThreads) void k_grad_b(const float *__restrict__ g,
                                                      float *__restrict__ dst, int64_t rows, int F,
                                                      int64_t ldg) {
   __shared__ float red[kThreads];
   const int c = blockIdx.y * 64 + (threadIdx.x & 63), phase = threadIdx.x >> 6;
+  const int cc = c < F ? c : F - 1;
   const int64_t r0 = (int64_t)blockIdx.x * kChunkRows;
   const int64_t r1 = (r0 + kChunkRows < rows) ? r0 + kChunkRows : rows;
   float s = 0.0f;
-  if (c < F)
-    for (int64_t r = r0 + phase; r < r1; r += 4) s = s + g[r * ldg + c];
+  for (int64_t r = r0 + phase; r < r1; r += 4 * kU) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t rr = r + 4 * u, rc = rr < r1 ? rr : r1 - 1;
+      v[u] = g[rc * ldg + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (r + 4 * u < r1) s = s + v[u];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (phase == 0 && c < F)
@@ -100,7 +144,8 @@ extern "C" int gwen_gcn_grad_weight_f32(const float *g, const float *x, float *g
   const int64_t nc = nchunks_for(rows);
   const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
   const int64_t ntiles = (int64_t)tiles_i * tiles_o;
-  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL) return GWEN_ERANGE;
+  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL || (Fin * Fout + 15) / 16 > 0x7fffffffLL)
+    return GWEN_ERANGE;
   if (nc > 1 && !partial) return GWEN_EINVAL;
   float *dst = nc > 1 ? partial : grad_W;
   dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
@@ -109,7 +154,7 @@ extern "C" int gwen_gcn_grad_weight_f32(const float *g, const float *x, float *g
   GWEN_LAUNCH_CHECK();
   if (nc > 1) {
     const int64_t count = Fin * Fout;
-    k_reduce_chunks<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(partial, grad_W, count, (int)nc);
+    k_reduce_chunks<<<(unsigned)((count + 15) / 16), kThreads, 0, st>>>(partial, grad_W, count, (int)nc);
     GWEN_LAUNCH_CHECK();
   }
   return GWEN_OK;
@@ -129,7 +174,7 @@ extern "C" int gwen_gcn_grad_bias_f32(const float *g, float *grad_b, int64_t row
   k_grad_b<<<grid, kThreads, 0, st>>>(g, dst, rows, (int)F, ldg);
   GWEN_LAUNCH_CHECK();
   if (nc > 1) {
-    k_reduce_chunks<<<(unsigned)((F + 255) / 256), 256, 0, st>>>(partial, grad_b, F, (int)nc);
+    k_reduce_chunks<<<(unsigned)((F + 15) / 16), kThreads, 0, st>>>(partial, grad_b, F, (int)nc);
     GWEN_LAUNCH_CHECK();
   }
   return GWEN_OK;

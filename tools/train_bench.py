@@ -1,0 +1,46 @@
+"""Training step (forward + L1 loss on masked rows + backward + Adam) of GNNModel on the c2 mesh and on the
+reference's own shape: ms per step.   python tools/train_bench.py [mesh|ref]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, gwen_amd
+which = sys.argv[1] if len(sys.argv) > 1 else "mesh"
+dev = "cuda:0"
+torch.manual_seed(23)
+if which == "mesh":
+    mesh = gwen_amd.geodesic_mesh(100, reorder="morton")
+    n, c, h = mesh.num_nodes, 64, 64
+    ei = torch.from_numpy(mesh.edge_index).to(dev)
+else:
+    n, c, h = 125, 16384, 1024
+    ei = torch.from_numpy(gwen_amd.complete_graph(n)).to(dev)
+model = gwen_amd.GNNModel(gwen_amd.GNNConfig(n, n, c, c, h)).to(dev).train()
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+x = torch.randn(n, c, device=dev)
+mask = torch.rand(n, device=dev) < 0.5
+def step():
+    opt.zero_grad(set_to_none=True)
+    out = model(x, ei)
+    loss = gwen_amd.loss_func(out, x, mask)
+    loss.backward()
+    opt.step()
+    return loss
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 30
+for _ in range(K):
+    step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+with torch.no_grad():
+    model.eval()
+    for _ in range(3):
+        model(x, ei)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        model(x, ei)
+    torch.cuda.synchronize()
+    df = (time.perf_counter() - t0) / K
+print(f"{which}: N={n} C={c} H={h}: training step {dt*1e3:.3f} ms, inference forward {df*1e3:.3f} ms")
