@@ -269,12 +269,12 @@ class GCNLayerFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x
             if ctx.needs_input_grad[0]:
-                gx = linear(gh, weight.t().contiguous())           # gh W
+                gx = linear(gh, weight.t().contiguous(), exact=False)          # gh W (3xbf16, split-K)
         else:
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(g, saved_in)                      # g^T (A~ x)
             if ctx.needs_input_grad[0]:
-                gagg = linear(g, weight.t().contiguous())          # g W
+                gagg = linear(g, weight.t().contiguous(), exact=False)         # g W
                 gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)
         return gx, gw, gb, None, None, None
 
