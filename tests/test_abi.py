@@ -51,7 +51,7 @@ def test_argument_validation_without_gpu(hip_lib):
     assert hip_lib.gwen_gcn_prep(8, None, 2 ** 31, 5, 1, 1.0, 1, 1, None, None, None, None, 1, None, 0, None) == -2
     assert hip_lib.gwen_relu_backward_f32(None, None, None, 0, None) == 0
     assert hip_lib.gwen_gcn_grad_workspace_floats(100, 8, 8) == 1
-    assert hip_lib.gwen_gcn_grad_workspace_floats(5000, 8, 4) == 5 * 32 + 1
+    assert hip_lib.gwen_gcn_grad_workspace_floats(5000, 8, 4) == 20 * 32 + 1      # 256-row chunks
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
