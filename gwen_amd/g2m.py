@@ -17,7 +17,7 @@ Inference only (no autograd through the bipartite layers).
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 import torch

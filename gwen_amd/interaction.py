@@ -20,7 +20,6 @@ Edge features live in the graph's STORED order (targets ascending): ``EdgeGraph.
 """
 from __future__ import annotations
 
-import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 

@@ -5,7 +5,6 @@ arithmetic step of the layer runs in libgwen_hip.so.
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Optional
 

@@ -1,7 +1,6 @@
 """K7 (gwen_gcn_small_layer_f32, gwen_gcn_dense_f32): whole GCNConv layers on graphs of at most 256 nodes
 with wide features -- the reference's own shape (complete graph over ~125 members,
 /root/reference/src/gwen/utils.py:175-176; hidden 1024, config.json:12) -- against the CPU oracle."""
-import numpy as np
 import pytest
 import torch
 
