@@ -59,6 +59,8 @@ def parse():
                    help="replay a captured hipGraph per step instead of issuing the 6 launches from the "
                         "C launcher (measured slower here: one graph launch costs more than 6 direct ones)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-edge-mlp", action="store_true",
+                   help="skip the side measurement of the InteractionNet edge-MLP kernel (K6)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return p.parse_args()
 
@@ -76,6 +78,42 @@ def algorithmic_bytes(kind, n, e, fin, fout):
     if kind == "layer":          # K4: gather at fin (E edges + self-loop), store at fout, indices, W
         return 4 * fin * (e + n) + 4 * fout * n + 8 * e + 8 * n + 4 * fin * fout
     raise KeyError(kind)
+
+
+def edge_mlp_side_measurement(mesh, f, dev, launches=30):
+    """K6 (gwen_mlp2_f32: gathers + edge MLP + residual + in-order sum to targets) on the mesh's edges
+    at width f: torch events on the launch stream around `launches` back-to-back launches."""
+    from gwen_amd import ops
+    from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
+    g = interaction_graph(torch.from_numpy(mesh.edge_index).to(dev), mesh.num_nodes, mesh.num_nodes)
+    n, e = mesh.num_nodes, g.num_edges
+    torch.manual_seed(23)
+    net = InteractionNet(f).to(dev)
+    x = torch.randn(n, f, device=dev)
+    ef = torch.randn(e, f, device=dev)
+    with torch.no_grad():
+        we, wa, wn, bn = net._weight_blocks()
+        p = ops.linear(x, wn, bn, exact=False)
+        run = lambda: mlp2(ef, we, net.edge_mlp[2].weight, net.edge_mlp[2].bias, g1=p[:, :f], idx1=g.src,   # noqa: E731
+                           g2=p[:, f:2 * f], idx2=g.dst, res=ef, graph=g)
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(launches):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+    t = a.elapsed_time(b) / launches * 1e-3
+    b_alg = 4 * f * (4 * e + n) + 8 * e + 4 * n      # e read, e' written, two gathered rows, agg, indices
+    return {"workload": f"InteractionNet edge kernel (K6), F={f}, same mesh: gathers + 2-layer edge MLP + "
+                        f"residual + in-order sum to targets, one launch", "edges": e,
+            "us_per_launch": round(t * 1e6, 1), "edge_updates_per_s": round(e / t),
+            "roofline": {"bound": "hbm" if f <= 64 else "mfma", "algorithmic_bytes": b_alg,
+                         "achieved_GBs": round(b_alg / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                         "frac_hbm": round(b_alg / t / 1e9 / HBM_PEAK_GBS, 4),
+                         "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
 def main():
@@ -221,6 +259,12 @@ def main():
         "members_per_s": members * args.steps / elapsed,
         "roofline": roofline,
     }
+
+    # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
+    # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline
+    # value above stays the reference's own layer (GCNConv) -------------------------------------------
+    if rank == 0 and world == 1 and not args.no_edge_mlp and h in (32, 64, 128, 256):
+        line["edge_mlp_block"] = edge_mlp_side_measurement(mesh, h, dev)
 
     # ---- CPU baseline: the torch oracle on this host's cores (rank 0, N = 1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
