@@ -107,12 +107,19 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30):
         torch.cuda.synchronize()
     t = a.elapsed_time(b) / launches * 1e-3
     b_alg = 4 * f * (4 * e + n) + 8 * e + 4 * n      # e read, e' written, two gathered rows, agg, indices
+    traffic = None                                    # HBM-side bytes per launch from the committed PMC passes
+    try:
+        tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
+        if (n, e) == (100002, 600000):
+            traffic = tf[f"k_mlp2<{f}, 2, 2, true>"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     return {"workload": f"InteractionNet edge kernel (K6), F={f}, same mesh: gathers + 2-layer edge MLP + "
                         f"residual + in-order sum to targets, one launch", "edges": e,
             "us_per_launch": round(t * 1e6, 1), "edge_updates_per_s": round(e / t),
             "roofline": {"bound": "hbm" if f <= 64 else "mfma", "algorithmic_bytes": b_alg,
                          "achieved_GBs": round(b_alg / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
-                         "frac_hbm": round(b_alg / t / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_hbm": round(b_alg / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
