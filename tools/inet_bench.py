@@ -74,7 +74,7 @@ def main():
     print(f"  without aggregation       {t_edge_noagg:8.1f} us")
     print(f"  without gathers either    {t_edge_plain:8.1f} us")
     print(f"node MLP (K6)               {t_node:8.1f} us")
-    print(f"whole block (5 launches)    {t_block:8.1f} us   {E / t_block / 1e3:6.2f} G edges/s")
+    print(f"whole block (1 K3 + 2 K6)    {t_block:8.1f} us   {E / t_block / 1e3:6.2f} G edges/s")
 
 
 if __name__ == "__main__":
