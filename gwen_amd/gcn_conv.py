@@ -62,6 +62,7 @@ class GCNConv(nn.Module):
         self.improved, self.cached = improved, cached
         self.add_self_loops, self.normalize = add_self_loops, normalize
         self._cached_graph: Optional[GraphCSR] = None
+        self._packed = None                            # (weight identity/version, K7 image) for inference
         self.order = "auto"                            # "auto" | "transform_first" | "aggregate_first"
         if bias:
             self.bias = nn.Parameter(torch.empty(out_channels))
@@ -80,6 +81,7 @@ class GCNConv(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_cached_graph"] = None
+        state["_packed"] = None
         return state
 
     def graph_for(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor]) -> GraphCSR:
@@ -104,7 +106,20 @@ class GCNConv(nn.Module):
             graph = edge_index
         else:
             graph = self.graph_for(x, edge_index, edge_weight)
-        return gcn_layer(x, self.lin.weight, self.bias, graph, relu=relu, order=self.order)
+        return gcn_layer(x, self.lin.weight, self.bias, graph, relu=relu, order=self.order,
+                         packed=self._packed_weight(graph))
+
+    def _packed_weight(self, graph: GraphCSR):
+        """Inference on a small graph (K7): the weight's fragment-ordered image, re-packed only when the
+        weight changed.  None while training (the weight changes every step) and on large graphs."""
+        if torch.is_grad_enabled() or self.order != "auto" or graph.dense() is None:
+            return None
+        w = self.lin.weight
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if self._packed is None or self._packed[0] != key:
+            from .forward import pack_weight
+            self._packed = (key, pack_weight(w))
+        return self._packed[1]
 
     def extra_repr(self) -> str:
         return f"{self.in_channels}, {self.out_channels}"

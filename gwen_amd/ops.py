@@ -226,7 +226,7 @@ class GCNLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], graph: GraphCSR,
-                relu: bool, order: str) -> Tensor:
+                relu: bool, order: str, packed: Optional[Tensor] = None) -> Tensor:
         fout, fin = weight.shape
         if order == "auto":
             if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout):
@@ -236,7 +236,7 @@ class GCNLayerFunction(torch.autograd.Function):
             else:
                 order = "aggregate_first" if fin < fout else "transform_first"
         if order == "small":
-            out = small_layer(graph, x, weight, bias, relu)
+            out = small_layer(graph, x, weight, bias, relu, packed=packed)
             saved_in = x
         elif order in ("fused", "fused_exact"):
             out = layer_fused(graph, x, weight, bias, relu, exact=(order == "fused_exact"))
@@ -275,13 +275,13 @@ class GCNLayerFunction(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gagg = linear(g, weight.t().contiguous(), exact=False)         # g W
                 gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def gcn_layer(x: Tensor, weight: Tensor, bias: Optional[Tensor], graph: GraphCSR,
-              relu: bool = False, order: str = "auto") -> Tensor:
+              relu: bool = False, order: str = "auto", packed: Optional[Tensor] = None) -> Tensor:
     _require(x, "x")
     _require(weight, "weight")
     if x.device != weight.device or x.device != graph.device:
         raise RuntimeError("x, weight and the graph must be on the same device")
-    return GCNLayerFunction.apply(x, weight, bias, graph, relu, order)
+    return GCNLayerFunction.apply(x, weight, bias, graph, relu, order, packed)
