@@ -326,10 +326,11 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     span(tn, nxt);
   }
   prefetch(cur);
-  for (;;) {
-    const int32_t n_rows = cur.e1 - cur.w0;                // valid rows of this pass (<= 0: none)
-    // ---- the gathered addends of this lane's rows (indices came with the prefetch) ---------------
-    float4_t add[C::TPW][C::NC];
+  // The gathered addends of a pass: requested at its top (the indices came with its prefetch).  At 256
+  // channels they are requested a pass EARLY instead -- right after the previous pass's second
+  // contraction -- which measured -9 % there (970 -> 885 us) and +4..6 % at 64 / 128 channels.
+  float4_t add[C::TPW][C::NC];
+  auto gather_addends = [&]() {
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k)
 #pragma unroll
@@ -342,6 +343,12 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
           add[k][n] += *reinterpret_cast<const float4_t *>(
               reinterpret_cast<const char *>(G2) + ((uint32_t)i2[k] * ldb2 + col(n) * 4u));
       }
+  };
+  if constexpr (C::STREAM) gather_addends();               // first pass: no earlier point exists
+  for (;;) {
+    const int32_t n_rows = cur.e1 - cur.w0;                // valid rows of this pass (<= 0: none)
+    // ---- the gathered addends of this lane's rows (indices came with the prefetch) ---------------
+    if constexpr (!C::STREAM) gather_addends();
     // phase 4's row bounds for this thread's first target row, requested early
     int32_t seg_s = 0, seg_e = 0;
     if constexpr (SEG) {
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
       tiles_mma_stream<F>(hhi, hlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W2), jw, lane, d);
     else
       tiles_mma<F>(hhi, hlo, tt0, mi, mh, w2hi, w2lo, d);
+    if constexpr (C::STREAM) gather_addends();             // for the NEXT pass (i1 / i2 hold its indices)
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
