@@ -68,6 +68,7 @@ struct Cfg {
   static constexpr int PB = ((FIN / 2) % 16 == 8 ? FIN / 2 : FIN / 2 + 8) * 2;   // split: pitch (bf16)
   static constexpr size_t lds_bytes = SPLIT ? (size_t)2 * BR * PB * 2 : (size_t)BR * PF * 4;
   static_assert(NWB % NJ == 0, "waves must tile the output columns");
+  static_assert(BR % RB == 0 && BR % kTile == 0, "a block is whole gather passes and whole row tiles");
 };
 
 template <int FIN, int FOUT, bool SPLIT, int BRMIN, bool UNI = false>
@@ -187,25 +188,23 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   }
 }
 
-template <int FIN, int FOUT, bool SPLIT>
-int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
-           const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
-           int64_t msx, int64_t mso, int relu, hipStream_t st) {
-  // rows per block: enough that W (read once per block) stays a small fraction of the gathered bytes
-  constexpr int BRMIN = FIN == 128 ? 128 : 64;     // 256: 64 rows keep two blocks per CU in LDS
+template <int FIN, int FOUT, bool SPLIT, int BRMIN>
+int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
+                const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
+                int64_t msx, int64_t mso, int relu, hipStream_t st, bool probe, int64_t *resident_out) {
   using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
-  int64_t blocks = (N + C::BR - 1) / C::BR;
-  if (FIN * FOUT >= 128 * 128) {       // wide layer: one resident set of blocks, W fetched once each
-    static int per_cu = 0;
-    if (per_cu == 0) {
-      int nbk = 0;
-      GWEN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nbk, reinterpret_cast<const void *>(&k_layer<FIN, FOUT, SPLIT, BRMIN, true>), C::NWB * 64, 0));
-      per_cu = nbk < 1 ? 1 : nbk;
-    }
-    const int64_t resident = (int64_t)256 * per_cu;
-    if (blocks > resident) blocks = resident;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nbk = 0;
+    GWEN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nbk, reinterpret_cast<const void *>(&k_layer<FIN, FOUT, SPLIT, BRMIN, true>), C::NWB * 64, 0));
+    per_cu = nbk < 1 ? 1 : nbk;
   }
+  const int64_t resident = (int64_t)256 * per_cu;
+  if (resident_out) *resident_out = resident;
+  if (probe) return GWEN_OK;
+  int64_t blocks = (N + C::BR - 1) / C::BR;
+  if (FIN * FOUT >= 128 * 128 && blocks > resident) blocks = resident;   // wide layer: one resident set
   dim3 grid((unsigned)blocks, (unsigned)members);
   if (!rowptr)      // uniform layout: row r is the group at 8 r
     k_layer<FIN, FOUT, SPLIT, BRMIN, true><<<grid, C::NWB * 64, 0, st>>>(
@@ -215,6 +214,45 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
         rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
+}
+
+template <int FIN, int FOUT, bool SPLIT>
+int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
+           const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
+           int64_t msx, int64_t mso, int relu, hipStream_t st) {
+#define GWEN_ROWS(BRV, PROBE, RES)                                                                  \
+  launch_rows<FIN, FOUT, SPLIT, BRV>(rowptr, col, val, x, W, bias, out, N, ldo, members, msx, mso,  \
+                                     relu, st, PROBE, RES)
+  if constexpr (FIN <= 64 && FOUT <= 64) {
+    // Narrow layers run as ONE round of co-resident blocks when a block size makes that possible: with
+    // 64-row blocks the c2 mesh needs 1 563 blocks against 1 024 resident ones (4 per CU at 64 -> 64),
+    // i.e. a full round plus a half-empty one of ~10 us each; 112-row blocks (893 of them) fit one round.
+    // Rows per block: the smallest of 64 / 96 / 112 / 128 (whole gather passes only) whose grid is
+    // co-resident, else 64.
+    int64_t res = 0;
+    const int64_t work = N * members;
+    { const int rc_ = GWEN_ROWS(64, true, &res); if (rc_ != GWEN_OK) return rc_; }
+    if ((work + 63) / 64 <= res || members > 1) return GWEN_ROWS(64, false, nullptr);
+    constexpr int RB = Cfg<FIN, FOUT, SPLIT, 64>::RB;      // a block is whole gather passes of RB rows
+    if constexpr (96 % RB == 0) {
+      { const int rc_ = GWEN_ROWS(96, true, &res); if (rc_ != GWEN_OK) return rc_; }
+      if ((N + 95) / 96 <= res) return GWEN_ROWS(96, false, nullptr);
+    }
+    if constexpr (112 % RB == 0) {
+      { const int rc_ = GWEN_ROWS(112, true, &res); if (rc_ != GWEN_OK) return rc_; }
+      if ((N + 111) / 112 <= res) return GWEN_ROWS(112, false, nullptr);
+    }
+    if constexpr (128 % RB == 0) {
+      { const int rc_ = GWEN_ROWS(128, true, &res); if (rc_ != GWEN_OK) return rc_; }
+      if ((N + 127) / 128 <= res) return GWEN_ROWS(128, false, nullptr);
+    }
+    return GWEN_ROWS(64, false, nullptr);
+  } else {
+    // rows per block: enough that W (read once per block) stays a small fraction of the gathered bytes
+    constexpr int BRMIN = FIN == 128 ? 128 : 64;     // 256: 64 rows keep two blocks per CU in LDS
+    return GWEN_ROWS(BRMIN, false, nullptr);
+  }
+#undef GWEN_ROWS
 }
 
 constexpr bool width_ok(int64_t f) { return f == 16 || f == 32 || f == 64 || f == 128 || f == 256; }
