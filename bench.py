@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--reorder", default="morton", choices=["none", "morton"])
     p.add_argument("--order", default="auto", choices=["auto", "unfused"],
                    help="auto: K4 fused layer where the widths allow; unfused: K3 + K2 per layer")
-    p.add_argument("--event-stride", type=int, default=20,
+    p.add_argument("--event-stride", type=int, default=40,
                    help="record per-kernel hipEvents on every n-th timed step (each pair of records "
                         "opens a ~10 us gap on the stream, so instrumenting every step would slow the "
                         "steps being timed)")
