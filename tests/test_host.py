@@ -169,3 +169,23 @@ def test_gather_members_single_process_is_identity():
         ensemble.gather_members(x, 4)
     out = ensemble.ensemble_rollout(lambda s: s + 1, x, 4, 3)
     assert torch.allclose(out, x + 4)
+
+
+def test_edge_features_of_the_forecaster_graphs():
+    """[length, displacement] per edge: reversing an edge flips the displacement and keeps the length;
+    grid -> mesh edges link every cell with its three corners (host-side geometry only)."""
+    import numpy as np
+    from gwen_amd.forecaster import edge_features
+    from gwen_amd.g2m import grid_mesh_edges
+    from gwen_amd.mesh import geodesic_mesh
+    m = geodesic_mesh(3)
+    f = edge_features(m.pos, m.pos, m.edge_index)
+    assert f.shape == (m.num_edges, 4) and f.dtype == np.float32
+    assert np.allclose(f[:, 0], np.linalg.norm(f[:, 1:], axis=1), atol=1e-6)
+    rev = edge_features(m.pos, m.pos, m.edge_index[::-1])
+    assert np.allclose(rev[:, 0], f[:, 0]) and np.allclose(rev[:, 1:], -f[:, 1:])
+    g2m, m2g = grid_mesh_edges(m)
+    cell = m.pos[m.faces].mean(axis=1)
+    a, b = edge_features(cell, m.pos, g2m), edge_features(m.pos, cell, m2g)
+    assert np.allclose(a[:, 0], b[:, 0]) and np.allclose(a[:, 1:], -b[:, 1:], atol=1e-6)
+    assert a[:, 0].max() < 2.0 / 3 + 0.5                       # a corner is close to its cell centre
