@@ -238,3 +238,33 @@ def test_ensemble_forecast_single_rank(ga):
     assert a.shape == (3, m.faces.shape[0], 8) and torch.equal(a, b)
     want = torch.stack([model.rollout(xm[i], graphs, 2)[-1] for i in range(3)])
     assert torch.equal(a, want)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_interaction_block_on_random_bipartite_graphs(ga, seed):
+    """Random shapes: skewed target degrees (empty rows, rows longer than several passes), ragged row
+    counts around the 64-row pass, every supported width and activation."""
+    from gwen_amd.interaction import InteractionNet, interaction_graph
+    from oracle import interaction_oracle as IO
+    rng = np.random.default_rng(1000 + seed)
+    F = [32, 64, 128, 256][seed % 4]
+    act = ["silu", "relu", "none"][seed % 3]
+    aggr = ["sum", "mean"][seed % 2]
+    ns, nd = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    e = int(rng.integers(1, 3000))
+    p = rng.random(nd) ** 4 + 1e-9                       # a few heavy targets, many light or empty ones
+    dst = rng.choice(nd, size=e, p=p / p.sum())
+    src = rng.integers(0, ns, size=e)
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    torch.manual_seed(seed)
+    net = InteractionNet(F, act, aggr)
+    g = torch.Generator().manual_seed(seed)
+    xs, xd, ef = torch.randn(ns, F, generator=g), torch.randn(nd, F, generator=g), torch.randn(e, F, generator=g)
+    sd = {k: v.double() for k, v in net.state_dict().items()}
+    want_x, want_e = IO.interaction(xs.double(), xd.double(), ef.double(), ei, sd, act, aggr)
+    graph = interaction_graph(ei.to(DEV), ns, nd)
+    net = net.to(DEV)
+    with torch.no_grad():
+        got_x, got_e = net(xs.to(DEV), xd.to(DEV), graph.sort_edges(ef.to(DEV)), graph)
+    assert rel_err(got_x, want_x) <= REL_TOL
+    assert rel_err(graph.unsort_edges(got_e), want_e) <= REL_TOL

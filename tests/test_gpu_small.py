@@ -148,3 +148,26 @@ def test_weighted_small_graph(ga):
         g = ga.prepare_graph(ei.to(DEV), n, ew.to(DEV), improved=improved)
         got = ops.small_layer(g, x.to(DEV), w.to(DEV), b.to(DEV))
         assert rel_err(got, want) <= 2e-5
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_small_layer_on_random_graphs_and_shapes(ga, seed):
+    """Random node counts up to 256, random multigraphs, random (Fin, Fout) among the supported multiples."""
+    import numpy as np
+    from gwen_amd import ops
+    from gwen_amd.forward import pack_weight
+    from helpers import random_multigraph
+    from oracle import gcn_oracle as O
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(1, 257))
+    fin = int(rng.integers(1, 40)) * 32
+    fout = int(rng.integers(1, 40)) * 16
+    e = int(rng.integers(0, 6 * n + 1))
+    ei = random_multigraph(n, e, seed=seed, self_loops=int(rng.integers(0, 5)), dup=int(rng.integers(0, 9)) if e else 0)
+    w, b = make_params(fin, fout, seed=seed)
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(seed))
+    want = torch.relu(O.gcn_conv(x.double(), ei, w.double(), b.double()))
+    g = ga.prepare_graph(ei.to(DEV), n)
+    got = ops.small_layer(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+    packed = ops.small_layer(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True, packed=pack_weight(w.to(DEV)))
+    assert rel_err(got, want) <= 2e-5 and torch.equal(got, packed)
