@@ -290,10 +290,17 @@ def main():
         med = sorted(ts)[len(ts) // 2]
         got = (out if out.dim() == 2 else out[0]).cpu()
         err = float((got - yc).abs().max() / yc.abs().max())
+        cpu_model = "unknown CPU"
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+        except (OSError, StopIteration):
+            pass
         line["cpu_baseline"] = {
             "value": layers * e / med, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": f"{reps} full GNNModel.forward passes of the same c2 workload (1 member), median "
-                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU, oracle/gcn_oracle.py",
+                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU ({cores} threads on {cpu_model}), "
+                      f"oracle/gcn_oracle.py",
             "gpu_vs_oracle_rel_err": err,
         }
     if rank == 0:
