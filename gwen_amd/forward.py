@@ -130,6 +130,12 @@ class StackForward:
             d.packed = 0 if img is None else img.data_ptr()
             self._keep.append(img)
         self.fin, self.fout = self.desc[0].fin, self.desc[len(layers) - 1].fout
+        # the launcher's own test for the K7 path (small graph, every layer AUTO and of a supported shape):
+        # when it holds the grouped layout is never read, so it is not built (a kernel and a read-back
+        # per fresh graph -- the reference's loaders hand over a new edge_index per batch)
+        self._small = graph.dense() is not None and all(
+            d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, d.fin, d.fout)
+            for d in self.desc)
         self._scratch: Optional[Tensor] = None
         self._scratch_key = None
 
@@ -165,7 +171,7 @@ class StackForward:
             out = torch.empty(*x.shape[:-1], self.fout, dtype=torch.float32, device=dev)
         scratch = self._scratch_for(members, dev)
         g = self.graph
-        gr, gc, gv = g.grouped()
+        gr, gc, gv = (None, None, None) if self._small else g.grouped()
         with torch.cuda.device(dev):
             rc = _lib.lib().gwen_gnn_forward_f32(
                 _ptr(g.rowptr), _ptr(g.col), _ptr(g.val), _ptr(gr), _ptr(gc), _ptr(gv), _ptr(g.dense()), n,
