@@ -42,3 +42,4 @@ print(f"members={n} channels={c} hidden={h}")
 print(f"  swapped GCNConv, fresh edge_index per forward : {timed(lambda: swapped(True)):8.1f} us")
 print(f"  swapped GCNConv, one edge_index tensor        : {timed(lambda: swapped(False)):8.1f} us")
 print(f"  gwen_amd.GNNModel (whole stack, one C call)   : {timed(lambda: model(x, swapped.ei)):8.1f} us")
+print(f"  gwen_amd.GNNModel, fresh edge_index per forward: {timed(lambda: model(x, ei_host.to(dev))):8.1f} us")
