@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "c2"): synthetic ICON-CH1-scale geodesic mesh, nu = 100 ->
-N = 100 002 nodes, E = 600 000 directed edges; GNNModel(channels 64 -> hidden 64 -> 64), fp32,
+Headline workload (BASELINE.json configs[1], "c2"): synthetic ICON-CH1-scale geodesic mesh, nu = 100 ->
+N = 100 002 nodes, E = 600 000 directed edges; GNNModel(channels 64 -> hidden 64 -> 64), fp32 storage,
 random-init weights (seed 23), 1 ensemble member per GPU.  One STEP = one GNNModel.forward of every
 local member = 6 GCNConv layers = 6 message+aggregate passes over the E mesh edges (plus their dense
 projections, bias and ReLU).  value = members * 6 * E * K / t  [edge passes per second, whole job].
@@ -14,12 +14,21 @@ Inputs, weights and the prepared graph are resident in HBM before the timed regi
 members are sharded one per rank (weak scaling), there is no collective on the data path, and the
 single RCCL all-gather of the final states sits INSIDE the timed region, after the last step.
 
-Two extra objects ride on the JSON line (see DESIGN.md "Measurement"):
-  roofline     -- the dominant kernel (by summed time) of the timed region: algorithmic bytes per
-                  launch / its average duration from hipEvents the launcher records around every
-                  kernel launch (on the launch stream) inside the timed region, against 8 TB/s.
-  cpu_baseline -- the torch oracle (kind "port": the reference's PyG is not installable) timed on
-                  this host's cores for the same workload, rank 0, N = 1 only.
+Extra objects on the JSON line (DESIGN.md "Measurement"):
+  roofline      -- dominant kernel of the c2 step.  c2's working set (3 x 25.6 MB) lives in the L2s and the
+                   256 MiB Infinity Cache, so the ceiling that binds is the L2 ("bound": "l2", peak 34.5
+                   TB/s, MI355X_MICROARCH.md): achieved = bytes the kernel pulls through L1/L2 (SURVEY 8(d)'s
+                   algorithmic bytes) / its mean duration from >= 10 hipEvent samples.  The compulsory
+                   (HBM-side) figure rides along as frac_hbm_compulsory.
+  hbm_leg       -- the same path where HBM IS the bound (N = 1 only, outside the timed region): BASELINE
+                   config c3's stack (4 chained 256 -> 256 GCN layers + ReLU) on 4 members per GPU -- the
+                   per-GPU load of config c5 -- 410 MB per activation buffer, far beyond the Infinity Cache.
+                   Its roofline: compulsory bytes (every input, output, index and weight byte once) / mean
+                   kernel duration / 8 TB/s; traffic = PMC bytes from the committed rocprofv3 passes.
+  exact_f32     -- the c2 step with every contraction on the fp32-input MFMA (order "fused_exact").
+  cpu_baseline  -- the torch oracle (kind "port": the reference's PyG is not installable) timed on this
+                   host's cores, all cores and one thread, rank 0, N = 1 only.
+  allgather     -- N > 1: duration and bus bandwidth of the one collective, ranks seen.
 """
 from __future__ import annotations
 
@@ -37,6 +46,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
+L2_GATHER_GBS = 17800.0        # same guide, "Indexed rows": rows served by the XCD's L2, 16.8-18.8 TB/s chip-wide
+MIN_SAMPLES = 10
 
 
 def parse():
@@ -48,26 +60,34 @@ def parse():
     p.add_argument("--channels", type=int, default=64)
     p.add_argument("--hidden", type=int, default=64)
     p.add_argument("--members-per-gpu", type=int, default=1)
-    p.add_argument("--reorder", default="morton", choices=["none", "morton"])
-    p.add_argument("--order", default="auto", choices=["auto", "unfused"],
-                   help="auto: K4 fused layer where the widths allow; unfused: K3 + K2 per layer")
+    p.add_argument("--reorder", default="hilbert", choices=["none", "morton", "hilbert"])
+    p.add_argument("--order", default="auto", choices=["auto", "unfused", "fused_exact"],
+                   help="auto: fused kernels, 3xbf16 contraction; fused_exact: fp32-input MFMA; "
+                        "unfused: K3 + K2 per layer")
     p.add_argument("--event-stride", type=int, default=40,
                    help="record per-kernel hipEvents on every n-th timed step (each pair of records "
                         "opens a ~10 us gap on the stream, so instrumenting every step would slow the "
-                        "steps being timed)")
+                        "steps being timed); more instrumented steps follow the timed region until "
+                        f"every kernel has {MIN_SAMPLES} samples")
     p.add_argument("--graph", action="store_true",
-                   help="replay a captured hipGraph per step instead of issuing the 6 launches from the "
-                        "C launcher (measured slower here: one graph launch costs more than 6 direct ones)")
+                   help="replay a captured hipGraph per step instead of issuing the launches from the C "
+                        "launcher (measured slower here: one graph launch costs more than 6 direct ones)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-edge-mlp", action="store_true",
                    help="skip the side measurement of the InteractionNet edge-MLP kernel (K6)")
-    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    p.add_argument("--no-hbm-leg", action="store_true")
+    p.add_argument("--no-exact", action="store_true")
+    p.add_argument("--hbm-members", type=int, default=4)
+    p.add_argument("--hbm-channels", type=int, default=256)
+    p.add_argument("--hbm-layers", type=int, default=4)
+    p.add_argument("--hbm-steps", type=int, default=12)
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU baseline leg")
     return p.parse_args()
 
 
 def algorithmic_bytes(kind, n, e, fin, fout):
-    """B_alg = gathered source rows + self-loop row + output row + int32 col + fp32 weight
-    per stored entry + rowptr + (K3: x read, W read, h written)."""
+    """bytes the kernel pulls through the L1/L2 path = gathered source rows + self-loop row +
+    output row + int32 col + fp32 weight per stored entry + rowptr (+ K3: x read, W read, h written)."""
     if kind == "propagate":      # K2 at width F = fin = fout
         f = fin
         return 4 * f * (e + 2 * n) + 8 * e + 8 * n
@@ -75,9 +95,62 @@ def algorithmic_bytes(kind, n, e, fin, fout):
         return 4 * n * (fin + fout) + 4 * fin * fout
     if kind == "chain":          # K5: gather at fin (E edges + self-loop), store at fout, indices
         return 4 * fin * (e + n) + 4 * fout * n + 8 * e + 8 * n
-    if kind == "layer":          # K4: gather at fin (E edges + self-loop), store at fout, indices, W
+    if kind in ("layer", "wide"):    # K4 / K8: gather at fin, store at fout, indices, W
         return 4 * fin * (e + n) + 4 * fout * n + 8 * e + 8 * n + 4 * fin * fout
     raise KeyError(kind)
+
+
+def compulsory_bytes(kind, n, e, fin, fout, members=1):
+    """Every input, output, index and weight byte exactly once: what must cross the HBM interface when
+    nothing is resident."""
+    idx = 8 * (e + n) + 4 * n                        # col + val per stored entry, rowptr
+    if kind == "linear":
+        return 4 * members * n * (fin + fout) + 4 * fin * fout
+    if kind == "propagate":
+        return 8 * members * n * fin + idx
+    return 4 * members * n * (fin + fout) + idx + 4 * fin * fout
+
+
+def pmc_traffic(tag_prefixes):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/traffic.json, written
+    by tools/collect_traffic.py from two separate rocprofv3 --pmc runs of this command)."""
+    try:
+        tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
+    except (OSError, KeyError, ValueError):
+        return None
+    for k_, v in tf.items():
+        if any(k_.startswith(t) for t in tag_prefixes):
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
+class Sampler:
+    """Per-kernel durations from hipEvents the launcher records around every launch."""
+
+    def __init__(self, ga, max_launches):
+        self.ga, self.max_launches = ga, max_launches
+        self.sets = []
+
+    def new(self):
+        ev = self.ga.KernelEvents(self.max_launches)
+        self.sets.append(ev)
+        return ev
+
+    def summary(self, dev):
+        over = self.ga.event_bracket_overhead(dev)
+        summ = {}
+        for evs in self.sets:
+            for kind, layer, fin, fout, sec in evs.durations():
+                cnt, tot = summ.get((kind, fin, fout), (0, 0.0))
+                summ[(kind, fin, fout)] = (cnt + 1, tot + max(sec - over, 0.0))
+        return summ, over
+
+    def min_samples(self):
+        counts = {}
+        for evs in self.sets:
+            for kind, layer, fin, fout, _ in evs.durations():
+                counts[(kind, fin, fout)] = counts.get((kind, fin, fout), 0) + 1
+        return min(counts.values()) if counts else 0
 
 
 def edge_mlp_side_measurement(mesh, f, dev, launches=30):
@@ -106,21 +179,69 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30):
         b.record()
         torch.cuda.synchronize()
     t = a.elapsed_time(b) / launches * 1e-3
-    b_alg = 4 * f * (4 * e + n) + 8 * e + 4 * n      # e read, e' written, two gathered rows, agg, indices
-    traffic = None                                    # HBM-side bytes per launch from the committed PMC passes
-    try:
-        tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
-        if (n, e) == (100002, 600000):
-            traffic = tf[f"k_mlp2<{f}, 2, 2, true>"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    b_l2 = 4 * f * (4 * e + n) + 8 * e + 4 * n        # e read, e' written, two gathered rows, agg, indices
+    b_comp = 4 * f * (2 * e + 2 * n) + 12 * e + 4 * n  # e, e' once; x, agg once; src/dst/rowptr
     return {"workload": f"InteractionNet edge kernel (K6), F={f}, same mesh: gathers + 2-layer edge MLP + "
                         f"residual + in-order sum to targets, one launch", "edges": e,
             "us_per_launch": round(t * 1e6, 1), "edge_updates_per_s": round(e / t),
-            "roofline": {"bound": "hbm" if f <= 64 else "mfma", "algorithmic_bytes": b_alg,
-                         "achieved_GBs": round(b_alg / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
-                         "frac_hbm": round(b_alg / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "roofline": {"bound": "hbm" if f <= 64 else "mfma", "compulsory_bytes": b_comp,
+                         "achieved_GBs": round(b_comp / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                         "frac": round(b_comp / t / 1e9 / HBM_PEAK_GBS, 4),
+                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([f"k_mlp2<{f},"]),
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
+
+
+def hbm_leg(ga, mesh, graph, args, dev):
+    """BASELINE c3's processor stack at c5's per-GPU member count: the regime where HBM bounds the path."""
+    n, e = mesh.num_nodes, mesh.num_edges
+    f, m, nl = args.hbm_channels, args.hbm_members, args.hbm_layers
+    torch.manual_seed(23)
+    layers = []
+    for _ in range(nl):
+        conv = ga.GCNConv(f, f).to(dev)
+        with torch.no_grad():
+            conv.bias.normal_(0.0, 0.1)
+        layers.append((conv.lin.weight.detach(), conv.bias.detach(), True, "auto"))
+    plan = ga.StackForward(layers, graph)
+    x = torch.stack([torch.randn(n, f, generator=torch.Generator().manual_seed(123 + k)) for k in range(m)]).to(dev)
+    out = plan.run(x)
+    for _ in range(2):
+        plan.run(x, out=out)
+    torch.cuda.synchronize()
+    samp = Sampler(ga, 2 * nl)
+    steps = max(args.hbm_steps, (MIN_SAMPLES + nl - 1) // nl)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run(x, out=out, events=samp.new())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    summ, over = samp.summary(dev)
+    dom = max(summ, key=lambda k: summ[k][1])
+    cnt, tot = summ[dom]
+    kind, fin, fout = dom
+    avg = tot / cnt
+    comp = compulsory_bytes(kind, n, e, fin, fout, m)
+    ws_mib = 2 * 4 * m * n * f / 2 ** 20
+    tags = {"wide": [f"k_wide<{fin}, {fout},"], "layer": [f"k_layer<{fin}, {fout},"],
+            "propagate": ["k_propagate<"], "linear": ["k_linear<"], "chain": [f"k_chain<{fin},"]}[kind]
+    # one member against the CPU oracle's first layer would take minutes at this width; parity at this size
+    # is tests/test_gpu_wide.py::test_c3_layer_at_config_size_four_members
+    return {
+        "workload": f"c3 stack at c5's per-GPU load: {nl} chained GCN layers {f}->{f} + ReLU, {m} members, "
+                    f"nu={args.nu} N={n} E={e}; {ws_mib:.0f} MiB in+out per layer (Infinity Cache: 256 MiB)",
+        "members": m, "channels": f, "layers": nl, "steps": steps,
+        "ms_per_step": round(dt * 1e3, 4),
+        "edges_per_s": round(m * nl * e / dt),
+        "roofline": {"bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}] x {m} members",
+                     "achieved": round(comp / avg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(comp / avg / 1e9 / HBM_PEAK_GBS, 4),
+                     "compulsory_bytes_per_launch": comp, "avg_launch_us": round(avg * 1e6, 2),
+                     "samples": cnt, "traffic": pmc_traffic(tags),
+                     "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                       "of this command, gfx950 corrections applied)",
+                     "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2)
+                                        for k, v in sorted(summ.items())}},
+    }
 
 
 def main():
@@ -155,10 +276,18 @@ def main():
             if p_.dim() == 1:
                 p_.normal_(0.0, 0.1)                                 # exercise the bias path
     model = model.to(dev).eval()
-    if args.order == "unfused":
+
+    def set_order(which):
         for mod in model.modules():
             if isinstance(mod, gwen_amd.GCNConv):
-                mod.order = "aggregate_first" if mod.in_channels < mod.out_channels else "transform_first"
+                if which == "unfused":
+                    mod.order = "aggregate_first" if mod.in_channels < mod.out_channels else "transform_first"
+                elif which == "fused_exact":
+                    mod.order = "fused_exact" if gwen_amd.ops.layer_supported(mod.in_channels, mod.out_channels) else \
+                        ("aggregate_first" if mod.in_channels < mod.out_channels else "transform_first")
+                else:
+                    mod.order = "auto"
+    set_order(args.order)
     x = torch.stack([torch.randn(n, c, generator=torch.Generator().manual_seed(23 + m))
                      for m in range(lo, hi)]).to(dev)
     if m_local == 1:
@@ -172,8 +301,9 @@ def main():
     plan = gwen_amd.StackForward(model.stack(), graph)
     out = plan.run(x)                                                 # allocates scratch + output
     stride = max(1, args.event_stride)                                # events on every stride-th step
+    samp = Sampler(gwen_amd, 2 * layers)
     n_sets = (args.steps + stride - 1) // stride
-    ev_sets = [gwen_amd.KernelEvents(2 * layers) for _ in range(n_sets)]
+    ev_sets = [samp.new() for _ in range(n_sets)]
 
     graphed = gwen_amd.GraphedForward(plan, x) if args.graph else None
     if graphed is not None:
@@ -204,7 +334,13 @@ def main():
     for i in range(args.steps):
         step(ev_sets[i // stride] if i % stride == 0 else None)
     final = out if out.dim() == 3 else out.unsqueeze(0)
-    gathered = ensemble.gather_members(final, members) if world > 1 else final
+    if world > 1:
+        ag0, ag1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ag0.record()
+        gathered = ensemble.gather_members(final, members)
+        ag1.record()
+    else:
+        gathered = final
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -214,93 +350,149 @@ def main():
     elapsed = float(elapsed.item())
     assert gathered.shape[0] == members and torch.isfinite(gathered).all()
 
-    # a bracket = kernel + one event record's worth of stream time: calibrate the latter on empty
-    # brackets and take it off (agrees with rocprofv3's kernel-only durations within 0.4 us)
-    ev_over = gwen_amd.event_bracket_overhead(dev)
-    summ = {}
-    for evs in ev_sets:
-        for kind, layer, fin, fout, sec in evs.durations():
-            cnt, tot = summ.get((kind, fin, fout), (0, 0.0))
-            summ[(kind, fin, fout)] = (cnt + 1, tot + max(sec - ev_over, 0.0))
+    allgather = None
+    if world > 1:
+        ag_ms = torch.tensor([ag0.elapsed_time(ag1)], dtype=torch.float64, device=dev)
+        seen = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ag_ms, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        per_rank = final.numel() * 4
+        allgather = {"ms": round(float(ag_ms.item()), 4), "bytes_per_rank": per_rank,
+                     "busbw_GBs": round(per_rank * (world - 1) / (float(ag_ms.item()) * 1e-3) / 1e9, 2),
+                     "ranks_seen": int(seen.item()), "world_size": dist.get_world_size(),
+                     "backend": dist.get_backend(),
+                     "note": "one all_gather_into_tensor of the final states, inside the timed region; "
+                             "busbw = bytes received per rank / time (each rank receives (world-1) shards)"}
 
-    # ---- roofline of the dominant kernel (events recorded inside the timed region) ---------------
+    # ---- more instrumented steps (outside the timed region) until every kernel has MIN_SAMPLES ------
+    while samp.min_samples() < MIN_SAMPLES:
+        step(samp.new())
+        torch.cuda.synchronize()
+    summ, ev_over = samp.summary(dev)
+
+    # ---- roofline of the dominant kernel of the c2 step: the L2 is the level that binds ---------------
     dom_key = max(summ, key=lambda k: summ[k][1])
     launches, total_s = summ[dom_key]
     kind, fin, fout = dom_key
-    b_alg = algorithmic_bytes(kind, n, e, fin, fout) * m_local
+    b_l2 = algorithmic_bytes(kind, n, e, fin, fout) * m_local
+    b_comp = compulsory_bytes(kind, n, e, fin, fout, m_local)
     avg_s = total_s / launches
-    achieved = b_alg / avg_s / 1e9
-    # HBM-side bytes per launch of that kernel from the committed PMC passes (tools/profile_bench.sh +
-    # tools/collect_traffic.py; FETCH_SIZE and WRITE_SIZE need separate rocprofv3 passes)
-    traffic = None
-    try:
-        tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
-        tag = {"layer": f"k_layer<{fin}, {fout},", "chain": f"k_chain<{fin},", "linear": "k_linear<",
-               "propagate": "k_propagate<"}[kind]
-        hits = [v["hbm_bytes_per_launch"] for k_, v in tf.items()
-                if k_.startswith(tag) and (kind != "chain" or k_.split(",")[1].strip() != "0"
-                                           and fout in (int(k_.split(",")[1]), int(k_.split(",")[2])))]
-        if hits and (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1):
-            traffic = hits[0]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    achieved = b_l2 / avg_s / 1e9
+    tag = {"layer": [f"k_layer<{fin}, {fout},"], "chain": [f"k_chain<{fin},"], "linear": ["k_linear<"],
+           "propagate": ["k_propagate<"], "wide": [f"k_wide<{fin}, {fout},"]}[kind]
+    default_c2 = (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1)
+    per_layer_us = {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())}
     roofline = {
-        "bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": round(avg_s * 1e6, 2),
-        "launches": launches, "event_record_overhead_us": round(ev_over * 1e6, 2),
-        "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())},
+        "bound": "l2", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
+        "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / L2_PEAK_GBS, 4),
+        "traffic": pmc_traffic(tag) if default_c2 else None,
+        "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this command)",
+        "l2_path_bytes_per_launch": b_l2, "frac_of_l2_gather_rate": round(achieved / L2_GATHER_GBS, 4),
+        "compulsory_bytes_per_launch": b_comp,
+        "frac_hbm_compulsory": round(b_comp / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+        "avg_launch_us": round(avg_s * 1e6, 2), "samples": launches,
+        "event_record_overhead_us": round(ev_over * 1e6, 2), "all_kernels_us": per_layer_us,
+        "why_l2": "the c2 working set (<= 3 x 25.6 MB) never leaves the L2s / Infinity Cache, so HBM does not "
+                  "bound this kernel; the HBM-bound measurement of the same path is hbm_leg",
     }
 
     value = members * layers * e * args.steps / elapsed
+    # one 64 -> 64 message+aggregate pass by itself (the last layer: a whole-layer kernel at 64 channels)
+    last_key = [k for k in summ if k[1] == h and k[2] == c and k[0] in ("layer", "wide")]
+    pass64 = None
+    if last_key:
+        cnt_, tot_ = summ[last_key[0]]
+        pass64 = round(m_local * e / (tot_ / cnt_))
     line = {
         "metric": "mesh edges/s (message+aggregate)", "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"c2: geodesic mesh nu={args.nu} N={n} E={e}, GNNModel forward "
-                               f"C={c} H={h} (6 GCNConv layers), {m_local} member/GPU",
+                               f"C={c} H={h} (6 GCNConv layers at widths "
+                               f"{'/'.join(str(min(a, b)) for a, b in widths)} gathered), {m_local} member/GPU",
                    "nodes": n, "edges": e, "channels": c, "hidden": h, "layers": layers,
-                   "members": members, "node_order": args.reorder, "kernel_order": args.order, "hip_graph": bool(args.graph),
+                   "members": members, "node_order": args.reorder, "kernel_order": args.order,
+                   "contraction": {"auto": "3xbf16-split (fp32 storage and accumulation; see exact_f32)",
+                                   "fused_exact": "fp32-input MFMA (exact fp32 products)",
+                                   "unfused": "3xbf16-split in K3"}[args.order],
+                   "hip_graph": bool(args.graph),
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
         "members_per_s": members * args.steps / elapsed,
+        "edges_per_s_64ch_pass": pass64,
         "roofline": roofline,
     }
+    if allgather is not None:
+        line["allgather"] = allgather
+
+    single = rank == 0 and world == 1
+    # ---- exact-fp32 sibling of the headline (outside the timed region) --------------------------------
+    if single and not args.no_exact and args.order == "auto":
+        set_order("fused_exact")
+        plan_x = gwen_amd.StackForward(model.stack(), graph)
+        out_x = plan_x.run(x)
+        for _ in range(5):
+            plan_x.run(x, out=out_x)
+        torch.cuda.synchronize()
+        k_x = max(20, min(args.steps, 100))
+        tx = time.perf_counter()
+        for _ in range(k_x):
+            plan_x.run(x, out=out_x)
+        torch.cuda.synchronize()
+        dtx = (time.perf_counter() - tx) / k_x
+        line["exact_f32"] = {"ms_per_step": round(dtx * 1e3, 5), "edges_per_s": round(members * layers * e / dtx),
+                             "contraction": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), order fused_exact",
+                             "steps": k_x,
+                             "max_rel_diff_vs_3xbf16": float((out_x - out).abs().max() / out_x.abs().max())}
+        set_order("auto")
+
+    # ---- HBM-bound leg ----------------------------------------------------------------------------------
+    if single and not args.no_hbm_leg:
+        line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev)
 
     # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline
     # value above stays the reference's own layer (GCNConv) -------------------------------------------
-    if rank == 0 and world == 1 and not args.no_edge_mlp and h in (32, 64, 128, 256):
+    if single and not args.no_edge_mlp and h in (32, 64, 128, 256):
         line["edge_mlp_block"] = edge_mlp_side_measurement(mesh, h, dev)
 
     # ---- CPU baseline: the torch oracle on this host's cores (rank 0, N = 1 only) ----------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
         from oracle import gcn_oracle as O
         ref = O.OracleGNNModel(O.OracleGNNConfig(n, n, c, c, h))
         ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
         xc = (x if x.dim() == 2 else x[0]).cpu()
         eic = torch.from_numpy(mesh.edge_index)
-        cores = torch.get_num_threads()
-        with torch.no_grad():
-            tw = time.perf_counter(); yc = ref(xc, eic); one = time.perf_counter() - tw   # warm-up
-            reps = max(1, min(20, int(args.cpu_seconds / max(one, 1e-3))))
-            ts = []
-            for _ in range(reps):
-                tw = time.perf_counter(); yc = ref(xc, eic); ts.append(time.perf_counter() - tw)
-        med = sorted(ts)[len(ts) // 2]
-        got = (out if out.dim() == 2 else out[0]).cpu()
-        err = float((got - yc).abs().max() / yc.abs().max())
         cpu_model = "unknown CPU"
         try:
             with open("/proc/cpuinfo") as fh:
                 cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
         except (OSError, StopIteration):
             pass
+
+        def cpu_leg(threads):
+            torch.set_num_threads(threads)
+            with torch.no_grad():
+                tw = time.perf_counter(); yc_ = ref(xc, eic); one = time.perf_counter() - tw   # warm-up
+                reps = max(1, min(20, int(args.cpu_seconds / max(one, 1e-3))))
+                ts = []
+                for _ in range(reps):
+                    tw = time.perf_counter(); yc_ = ref(xc, eic); ts.append(time.perf_counter() - tw)
+            return sorted(ts)[len(ts) // 2], reps, yc_
+
+        all_cores = torch.get_num_threads()
+        med, reps, yc = cpu_leg(all_cores)
+        med1, reps1, _ = cpu_leg(1)
+        torch.set_num_threads(all_cores)
+        got = (out if out.dim() == 2 else out[0]).cpu()
+        err = float((got - yc).abs().max() / yc.abs().max())
         line["cpu_baseline"] = {
-            "value": layers * e / med, "unit": "edges/s", "cores": cores, "kind": "port",
+            "value": layers * e / med, "unit": "edges/s", "cores": all_cores, "kind": "port",
             "sample": f"{reps} full GNNModel.forward passes of the same c2 workload (1 member), median "
-                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU ({cores} threads on {cpu_model}), "
+                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU ({all_cores} threads on {cpu_model}), "
                       f"oracle/gcn_oracle.py",
+            "one_thread": {"value": layers * e / med1, "cores": 1,
+                           "sample": f"{reps1} passes, median {med1*1e3:.1f} ms, torch.set_num_threads(1)"},
             "gpu_vs_oracle_rel_err": err,
         }
     if rank == 0:

@@ -33,11 +33,19 @@ class LaunchInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("layer", C.c_int32), ("fin", C.c_int32), ("fout", C.c_int32)]
 
 
+class GraphDesc(C.Structure):
+    """gwen_graph (include/gwen_hip.h)."""
+    _fields_ = [("N", C.c_int64), ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p),
+                ("g_rowptr", C.c_void_p), ("g_col", C.c_void_p), ("g_val", C.c_void_p),
+                ("dense", C.c_void_p), ("t_rows", C.c_void_p), ("t_lid", C.c_void_p),
+                ("t_val", C.c_void_p), ("union_max", C.c_int64)]
+
+
 ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
-KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN, KIND_SMALL = 2, 3, 4, 5, 6
+KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN, KIND_SMALL, KIND_WIDE = 2, 3, 4, 5, 6, 8
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer",
-              KIND_CHAIN: "chain", KIND_SMALL: "small"}
+              KIND_CHAIN: "chain", KIND_SMALL: "small", KIND_WIDE: "wide"}
 
 # name -> (restype, argtypes); mirrors include/gwen_hip.h one to one
 SIGNATURES = {
@@ -62,8 +70,13 @@ SIGNATURES = {
     "gwen_gcn_chain_supported": (_int, [_i64, _i64, _i64, _int]),
     "gwen_gcn_chain_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,
                                   _int, _i64, _i64, _i64, _vp]),
+    "gwen_gcn_tiles64_count": (_i64, [_i64]),
+    "gwen_gcn_tiles64": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gwen_gcn_wide_supported": (_int, [_i64, _i64]),
+    "gwen_gcn_wide_preferred": (_int, [_i64, _i64, _i64, _i64]),
+    "gwen_gcn_wide_layer_f32": (_int, [_vp] * 7 + [_i64] * 8 + [_int, _i64, _vp]),
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
-    "gwen_gnn_forward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
+    "gwen_gnn_forward_f32": (_int, [C.POINTER(GraphDesc), C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
                                     C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]),
     "gwen_event_create": (_int, [C.POINTER(C.c_void_p)]),

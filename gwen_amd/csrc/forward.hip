@@ -65,14 +65,17 @@ extern "C" int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members,
   return P.total;
 }
 
-extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
-                                    const int32_t *g_rowptr, const int32_t *g_col,
-                                    const float *g_val, const float *dense, int64_t N,
-                                    const gwen_layer_desc *layers, int32_t n_layers,
-                                    const float *x, float *out, float *scratch,
+extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_desc *layers,
+                                    int32_t n_layers, const float *x, float *out, float *scratch,
                                     int64_t scratch_floats, int64_t members, gwen_stream_t stream,
                                     void **events, gwen_launch_info *info, int32_t max_launches,
                                     int32_t *n_launches) {
+  if (!graph) return GWEN_EINVAL;
+  const int64_t N = graph->N;
+  const int32_t *rowptr = graph->rowptr, *col = graph->col, *g_rowptr = graph->g_rowptr,
+                *g_col = graph->g_col;
+  const float *val = graph->val, *g_val = graph->g_val, *dense = graph->dense;
+  const bool have_tiles = graph->t_rows && graph->t_lid && graph->t_val;
   if (N < 0 || members < 0 || n_layers <= 0 || !layers) return GWEN_EINVAL;
   Plan P;
   int rc = make_plan(N, members, layers, n_layers, &P);
@@ -160,9 +163,20 @@ extern "C" int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, c
     }
     const int o = resolve_order(L);
     if (o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) {
-      if (!have_grouped) return GWEN_EINVAL;
-      const bool chain = L.order == GWEN_ORDER_AUTO && !last && shrinking_auto(i + 1) &&
+      const bool chain = have_grouped && L.order == GWEN_ORDER_AUTO && !last && shrinking_auto(i + 1) &&
                          gwen_gcn_chain_supported(fi, fo, layers[i + 1].fout, 0);
+      if (!chain && L.order == GWEN_ORDER_AUTO && have_tiles &&
+          gwen_gcn_wide_preferred(N, members, fi, fo)) {        // K8: the same arithmetic as K4, tile-staged
+        float *dst = last ? out : buf[nbuf++ & 1];
+        GWEN_TRY(before(GWEN_KIND_WIDE, i, fi, fo));
+        GWEN_TRY(gwen_gcn_wide_layer_f32(graph->t_rows, graph->t_lid, graph->t_val, cur, L.W, L.bias, dst,
+                                         N, N, fi, fo, fo, members, N * fi, N * fo, L.relu,
+                                         graph->union_max, stream));
+        GWEN_TRY(after());
+        cur = dst;
+        continue;
+      }
+      if (!have_grouped) return GWEN_EINVAL;
       // a chained kernel stores the NEXT layer's input, never the stack's output
       float *dst = (last && !chain) ? out : buf[nbuf++ & 1];
       if (chain) {

@@ -1,0 +1,456 @@
+// K8 -- a whole WIDE GCNConv layer (+ReLU) per launch, tile-staged:   out = act( (A~ x) W^T + bias )
+//
+// Same contract as K4 (layer.hip; replaces lin -> index_select -> mul -> scatter_add_ -> + bias -> relu of
+// torch-geometric 2.3.1 GCNConv.forward as called from /root/reference/src/gwen/models_gnn.py:147-149,
+// :204-206), built for the regime K4 is weakest in: Fin >= 64 on a locality-ordered bounded-degree mesh,
+// where K4 pulls every gathered source row (~7 per destination row) through the vector L1 path
+// (measured 50-70 GB/s per CU: 49 us per 256-wide pass in cache, 2.9 TB/s of compulsory traffic once the
+// working set leaves the Infinity Cache).  Here a block owns TILES of 64 destination rows
+// (gwen_gcn_tiles64: per tile the union of the source rows its entries name, ~116 rows on the nu = 100
+// mesh in Morton order, and a 16-bit local id per entry) and
+//   * stages the union ONCE in LDS, 64 features (256 B per row) at a time, by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave instruction) -- 1.8x the compulsory
+//     bytes through the L1 path instead of 7x; the entries' weights and local ids ride the same DMA;
+//   * aggregates the 64 destination rows from LDS (8 ds_read_b128 per lane, fma chain in stored order:
+//     the same order and rounding as K4's gather), splits the sums into bf16 hi/lo images;
+//   * contracts the 64 x 64 chunk with W on the matrix cores (3xbf16, fp32 accumulate, as K4) while the
+//     DMA of the chunk after next is in flight and the next chunk is being aggregated;
+//   * adds bias / ReLU and stores after the last chunk.
+// One 8-wave block per CU walks its tiles persistently; ONE barrier per 64-feature chunk:
+//     top(s):  s_waitcnt vmcnt(0) (DMA of chunk s+1 landed), barrier
+//              [stores of the tile that finished in chunk s-1]
+//              issue DMA(s+2) -> stage[s % 2]          (free: aggregate(s) is behind the barrier)
+//              aggregate(s+1): stage[(s+1) % 2] -> A[(s+1) % 2]
+//              mfma(s):        A[s % 2] x W[:, chunk]  -> accumulators
+// The DMAs are issued by inline asm, so hipcc neither counts nor drains them (cdna_hip_programming.md
+// section 5 "Pipelining across barriers"); every other global read of the loop is a scalar load (the union
+// rows of the tile) and the only vector-memory instructions hipcc sees are the output stores.
+// XCD-aware: the tile list (members x tiles) is cut into 8 contiguous ranges, one per blockIdx % 8, and
+// the blocks of an XCD walk their range interleaved, so the halos of concurrently staged tiles meet in
+// that XCD's L2.
+// Numerics: identical to K4's 3xbf16 path term for term (same aggregation order, same split, same MFMA
+// sequence) -- tests compare the two bitwise.
+#include "common.h"
+#include <type_traits>
+
+#ifndef WEAVE_VALU
+#define WEAVE_VALU 2
+#endif
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = GWEN_TILE_ROWS;        // 64 destination rows per tile
+constexpr int kUCap = GWEN_TILE_UNION;       // 192 union slots per tile in t_rows
+constexpr int kFC = 64;                      // features per chunk
+constexpr int kStageAll = kUCap * kFC * 4 * 2;              // 98304 B of staging: 2 x 192 or 3 x 128 slots
+constexpr int kPB = 80;                      // A-chunk row pitch in bf16 (160 B: conflict-free 16-B reads)
+constexpr int kAImg = kRows * kPB * 2;       // one bf16 image (hi or lo) of a chunk: 10240 B
+constexpr int kABytes = 2 * kAImg;
+constexpr int kEntBytes = kRows * 8 * 4 + kRows * 8 * 2;   // weights fp32 + local ids u16 = 3072
+constexpr int kOffStage = 0;
+constexpr int kOffA = kOffStage + kStageAll;                // 98304
+constexpr int kOffEnt = kOffA + 2 * kABytes;                // 139264
+constexpr int kOffBias = kOffEnt + 3 * kEntBytes;           // 148480
+constexpr int kLds = kOffBias + 1024;                       // 149504
+
+__device__ inline void split4(const float4_t &a, bf16x4 &hi, bf16x4 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 h = (__bf16)a[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(a[i] - (float)h);
+  }
+}
+
+template <int N, typename F, int I = 0>
+__device__ inline void gwen_static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gwen_static_for<N, F, I + 1>(static_cast<F &&>(f));
+  }
+}
+
+// a wave-uniform pointer, pinned to SGPRs (an "s" asm operand is not moved there by hipcc when instruction
+// selection happened to compute it on the vector ALU)
+__device__ inline const char *uniform_ptr(const void *p) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
+}
+
+// one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) to LDS byte address dst + 16 l
+__device__ inline void glds16(const void *base, uint32_t voff, uint32_t dst) {
+  uint32_t keep;       // M0 is compiler-reserved: save and restore it inside the statement
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ inline void wait_vmcnt(int n) {
+  switch (n) {
+#define GWEN_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    GWEN_VM(1) GWEN_VM(2) GWEN_VM(3) GWEN_VM(4) GWEN_VM(5) GWEN_VM(6) GWEN_VM(7) GWEN_VM(8) GWEN_VM(9)
+    GWEN_VM(10) GWEN_VM(11) GWEN_VM(12) GWEN_VM(13) GWEN_VM(14) GWEN_VM(15) GWEN_VM(16) GWEN_VM(17)
+    GWEN_VM(18) GWEN_VM(19) GWEN_VM(20) GWEN_VM(21) GWEN_VM(22) GWEN_VM(23) GWEN_VM(24)
+#undef GWEN_VM
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// D = chunks of DMA in flight behind the one being aggregated: D = 2 needs unions of at most 128 rows
+// (3 stage buffers of 128 slots), D = 1 takes unions up to 192 (2 buffers of 192 slots).
+template <int FIN, int FOUT, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void k_wide(
+    const int32_t *__restrict__ t_rows, const uint16_t *__restrict__ t_lid,
+    const float *__restrict__ t_val, const float *__restrict__ x, const float *__restrict__ W,
+    const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
+    int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu) {
+  constexpr int KU = D == 2 ? 128 : kUCap;              // union slots staged per chunk
+  constexpr int NSTG = D + 1;                           // stage buffers
+  constexpr int kStageBytes = KU * kFC * 4;
+  constexpr int NC = FIN / kFC;                         // chunks per tile
+  constexpr int NJ = FOUT / 16;                         // 16-column output tiles
+  constexpr int CT = NJ >= NW ? NJ / NW : 1;            // column tiles per wave
+  constexpr int TSTEP = NJ >= NW ? 1 : NW / NJ;         // waves sharing a column tile split the row tiles
+  constexpr int NTT = 4 / TSTEP;                        // row tiles per wave
+  constexpr int KS = FIN / 32;                          // MFMA k-steps over the whole Fin
+  constexpr int NQ = KU / (4 * NW);                     // DMA wave instructions per wave and chunk
+  constexpr int NP = kRows / (4 * NW);                  // aggregate passes per wave and chunk
+  static_assert(NC >= 1 && 4 % TSTEP == 0 && (NJ % NW == 0 || NW % NJ == 0), "unsupported widths");
+  static_assert(NQ * 4 * NW == KU && NP * 4 * NW == kRows, "waves must tile the union and the rows");
+  static_assert(NSTG * kStageBytes <= kStageAll, "stage buffers exceed their LDS region");
+  __shared__ __attribute__((aligned(1024))) char lds[kLds];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int mi = lane & 15, mh = lane >> 4;
+
+  // ---- this block's tiles: the tile list is cut into one contiguous range per XCD (blockIdx % 8; with
+  // fewer than 8 blocks, per block) and the blocks of an XCD walk their range interleaved -----------------
+  const int nx = gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % nx, idx = blockIdx.x / nx;
+  const int nbx = (int)gridDim.x / nx + (xcd < (int)gridDim.x % nx ? 1 : 0);
+  const int g0 = (int)((int64_t)xcd * G / nx), g1 = (int)((int64_t)(xcd + 1) * G / nx);
+  if (g0 + idx >= g1) return;                                  // whole block: no barrier reached yet
+  const int ntl = (g1 - g0 - idx + nbx - 1) / nbx;             // >= 1
+  auto tile_of = [&](int i) { return g0 + idx + (i < ntl ? i : ntl - 1) * nbx; };   // clamped
+
+  // (member, tile in member) of global tile g without an integer division (G < 2^31, members < 2^23)
+  const float inv_t = 1.0f / (float)T;
+  auto split_tile = [&](int g, int &m, int &t) {
+    m = __builtin_amdgcn_readfirstlane((int)((float)g * inv_t));     // g is wave-uniform
+    t = g - m * T;
+    if (t < 0) { --m; t += T; }
+    if (t >= T) { ++m; t -= T; }
+    m = __builtin_amdgcn_readfirstlane(m);
+    t = __builtin_amdgcn_readfirstlane(t);
+  };
+
+  // ---- W fragments (this wave's CT x 16 output columns, all of Fin) -- as K4; bias -> LDS ---------------
+  const int jw = NJ >= NW ? wave : wave % NJ;                  // this wave's column tiles: CT jw .. + CT - 1
+  const int tt0 = NJ >= NW ? 0 : wave / NJ;                    // its first row tile
+  bf16x8 bhi[CT][KS], blo[CT][KS];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int j = CT * jw + ct;                                // adjacent tiles: full 128-B lines per row
+    const float *wrow = W + (int64_t)(j * 16 + mi) * FIN;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float *wp = wrow + 8 * (4 * ks + mh);
+      const float4_t w0 = *reinterpret_cast<const float4_t *>(wp);
+      const float4_t w1 = *reinterpret_cast<const float4_t *>(wp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 h = (__bf16)w0[e];
+        bhi[ct][ks][e] = h; blo[ct][ks][e] = (__bf16)(w0[e] - (float)h);
+        h = (__bf16)w1[e];
+        bhi[ct][ks][e + 4] = h; blo[ct][ks][e + 4] = (__bf16)(w1[e] - (float)h);
+      }
+    }
+  }
+  {
+    float *bl = reinterpret_cast<float *>(lds + kOffBias);
+    for (int f = threadIdx.x; f < FOUT; f += NW * 64) bl[f] = bias ? bias[f] : 0.0f;
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)       // every global load above is waited for here, not inside the pipeline
+      asm volatile("" : "+v"(bhi[ct][ks]), "+v"(blo[ct][ks]));
+
+  // ---- pipeline pieces ------------------------------------------------------------------------------------
+  // DMA of (tile g, chunk c) into stage[sb]; with c == 0 also the tile's entry weights / local ids into
+  // ent[eb].  Union slot k = 4 (NW q + wave) + (lane >> 4); a group of 4 slots past the union starts with
+  // -1 and is skipped.  Returns the number of DMA instructions this wave issued.
+  auto issue = [&](int g, int c, int sb, int eb) -> int {
+    int m, t;
+    split_tile(g, m, t);
+    const int32_t *rp = t_rows + (int64_t)t * kUCap + 4 * wave;   // wave-uniform: scalar loads
+    const char *xm = uniform_ptr(x + (int64_t)m * mstride_x);
+    int32_t r[4 * NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
+    // every row id in an SGPR before the first DMA (one batch of scalar loads, selects instead of branches)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      asm volatile("" : "+s"(r[4 * q]), "+s"(r[4 * q + 1]), "+s"(r[4 * q + 2]), "+s"(r[4 * q + 3]));
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (r[4 * q] >= 0) {
+        int32_t row = r[4 * q];
+        row = mh == 1 ? r[4 * q + 1] : row;
+        row = mh == 2 ? r[4 * q + 2] : row;
+        row = mh == 3 ? r[4 * q + 3] : row;
+        const uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c * kFC * 4 + mi * 16);
+        glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
+        ++n;
+      }
+    }
+    if (c == 0 && wave < 3) {
+      const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t * (kRows * 32) + wave * 1024
+                                 : reinterpret_cast<const char *>(t_lid) + (int64_t)t * (kRows * 16);
+      src = uniform_ptr(src);
+      glds16(src, (uint32_t)lane * 16, lds0 + kOffEnt + eb * kEntBytes + wave * 1024);
+      ++n;
+    }
+    return n;
+  };
+  // aggregate one chunk: 64 rows x 16 lanes (4 features each) = 1024 lanes of work = NP passes per wave
+  auto aggregate = [&](int sb, int ab, int eb) {
+    const char *ent = lds + kOffEnt + eb * kEntBytes;
+    const char *stg = lds + kOffStage + sb * kStageBytes + mi * 16;
+    u32x4 lid4[NP];
+    float4_t wgt[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                      // entry weights / local ids of every pass first
+      const int lr = 4 * NW * p + 4 * wave + mh;
+      lid4[p] = *reinterpret_cast<const u32x4 *>(ent + kRows * 32 + lr * 16);
+      wgt[p][0] = *reinterpret_cast<const float4_t *>(ent + lr * 32);
+      wgt[p][1] = *reinterpret_cast<const float4_t *>(ent + lr * 32 + 16);
+    }
+    float4_t acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                    // 4 NP row reads in flight, then their fma chains
+      float4_t v[NP][4];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t pair = lid4[p][2 * hf + (u >> 1)];
+          const uint32_t lid = (u & 1) ? (pair >> 16) : (pair & 0xffffu);
+          v[p][u] = *reinterpret_cast<const float4_t *>(stg + lid * (kFC * 4));
+        }
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = wgt[p][hf][u];
+          acc[p] = __builtin_elementwise_fma(float4_t{w, w, w, w}, v[p][u], acc[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int lr = 4 * NW * p + 4 * wave + mh;
+      bf16x4 h4, l4;
+      split4(acc[p], h4, l4);
+      char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
+      *reinterpret_cast<bf16x4 *>(a) = h4;
+      *reinterpret_cast<bf16x4 *>(a + kAImg) = l4;
+    }
+  };
+
+  f32x4 d[CT][NTT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < NTT; ++i) d[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Stores of a finished tile, issued AFTER the step's DMAs so that a later top-of-step wait can leave them
+  // in flight.  The waits count instructions, so the count must be exact: a tile whose 64 rows all exist is
+  // stored with every lane active (CT * NTT store instructions); the last tile of a member is stored under
+  // its row guard and drained at once.  Returns the number of stores left in flight.
+  auto store_tile = [&](int g) -> int {
+    int m, t;
+    split_tile(g, m, t);
+    float *om = out + (int64_t)m * mstride_o;
+    const bool whole = (t + 1) * kRows <= N;
+    const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
+#pragma unroll
+    for (int i = 0; i < NTT; ++i) {
+      const int r = t * kRows + (tt0 + i * TSTEP) * 16 + mi;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int j = CT * jw + ct;
+        float4_t o = float4_t{d[ct][i][0], d[ct][i][1], d[ct][i][2], d[ct][i][3]} +
+                     *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
+        }
+        float *dst = om + (int64_t)r * ldo + j * 16 + 4 * mh;
+        if (whole || r < N) *reinterpret_cast<float4_t *>(dst) = o;
+        d[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (!whole) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return -1;                                   // everything this wave issued so far has completed
+    }
+    return CT * NTT;
+  };
+
+  auto mfma = [&](int ab, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const char *abase = lds + kOffA + ab * kABytes;
+#pragma unroll
+    for (int ti = 0; ti < NTT; ++ti) {
+      const char *ap = abase + (((tt0 + ti * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(ap + k2 * 64);
+        const bf16x8 alo = *reinterpret_cast<const bf16x8 *>(ap + k2 * 64 + kAImg);
+        const int ks = 2 * c + k2;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], alo, d[ct][ti], 0, 0, 0);
+          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ct][ks], ahi, d[ct][ti], 0, 0, 0);
+          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], ahi, d[ct][ti], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- prologue: chunks 0 .. D in flight, aggregate(0) -------------------------------------------------
+  // chunk s = (tile s / NC, chunk s % NC) lives in stage[s % NSTG], its aggregate in A[s % 2], its tile's
+  // entries in ent[(s / NC) % 3]
+#pragma unroll
+  for (int s0 = 0; s0 <= D; ++s0) issue(tile_of(s0 / NC), s0 % NC, s0 % NSTG, (s0 / NC) % 3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  aggregate(0, 0, 0);
+
+  // ---- steady state: interval s = i NC + c ---------------------------------------------------------------
+  //   wait: DMA(s+1) landed -- every operation older than the newest D - 1 DMA batches and their stores
+  //   barrier; issue DMA(s+D+1) -> stage[s % NSTG] (chunk s was aggregated before the barrier);
+  //   stores of tile i-1 (c == 0); aggregate(s+1) -> A[(s+1) % 2]; mfma(s) on A[s % 2]
+  int sb = 0;                 // s % NSTG
+  int eb = 0;                 // i % 3
+  int young = 0;              // operations issued after DMA(s+1): they may stay in flight at the wait
+  int last = 0;               // operations of the previous interval (DMA batch + stores)
+  for (int i = 0; i < ntl; ++i) {
+    gwen_static_for<NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const int s = i * NC + c;
+      wait_vmcnt(young);
+      __syncthreads();
+      int n_dma = 0, n_st = 0;
+      {
+        constexpr int a = c + D + 1;
+        const int i2 = i + a / NC;
+        n_dma = issue(tile_of(i2), a % NC, sb, (eb + a / NC) % 3);
+      }
+      if (c == 0 && i > 0) n_st = store_tile(tile_of(i - 1));
+      // D = 1: only this interval's stores are younger than the DMA the next wait is for.
+      // D = 2: the previous interval's stores, this interval's DMAs and stores.
+      if (n_st < 0) { young = 0; last = 0; }                      // drained
+      else if (D == 1) { young = n_st; }
+      else { young = last + n_dma + n_st; last = n_st; }
+      {
+        // aggregate(s+1) and mfma(s) are independent: one basic block, and the scheduler is asked to weave
+        // them -- a few VALU instructions of the aggregation behind every MFMA -- so that the
+        // matrix pipe paces the step and the gathers / fma chains / bf16 splits run in its shadow
+        constexpr int a = c + 1;
+        mfma(s & 1, cc);      // first in program order: its LDS reads must not sit behind the aggregate's writes
+        aggregate(sb + 1 == NSTG ? 0 : sb + 1, (s + 1) & 1, (eb + a / NC) % 3);
+        constexpr int kMfma = NTT * 2 * CT * 3;
+#pragma unroll
+        for (int k = 0; k < kMfma; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, WEAVE_VALU, 0);     // a few VALU of the aggregation
+        }
+      }
+      sb = sb + 1 == NSTG ? 0 : sb + 1;
+    });
+    eb = eb + 1 == 3 ? 0 : eb + 1;
+  }
+  store_tile(tile_of(ntl - 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
+}
+
+template <int FIN, int FOUT, int NW, int D>
+int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, const float *x,
+           const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
+           int64_t msx, int64_t mso, int relu, hipStream_t st) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    GWEN_HIP_CHECK(hipGetDevice(&dev));
+    GWEN_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = n < 8 ? 8 : n;
+  }
+  const int64_t T = (N + kRows - 1) / kRows, G = T * members;
+  if (G >= (int64_t(1) << 31)) return GWEN_ERANGE;
+  const int64_t blocks = G < cus ? G : cus;
+  k_wide<FIN, FOUT, NW, D><<<(unsigned)blocks, NW * 64, 0, st>>>(t_rows, t_lid, t_val, x, W, bias, out,
+                                                                (int32_t)N, (int32_t)T, (int32_t)G, ldo,
+                                                                msx, mso, relu);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+constexpr bool fin_ok(int64_t f) { return f == 64 || f == 128 || f == 256; }
+constexpr bool fout_ok(int64_t f) { return f == 64 || f == 128 || f == 256; }
+
+}  // namespace
+
+extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
+  return fin_ok(Fin) && fout_ok(Fout) ? 1 : 0;
+}
+
+extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
+  if (!gwen_gcn_wide_supported(Fin, Fout) || N <= 0 || members <= 0) return 0;
+  return Fin >= 128 || N * members >= 300000 ? 1 : 0;
+}
+
+extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_lid,
+                                       const float *t_val, const float *x, const float *W,
+                                       const float *bias, float *out, int64_t N, int64_t N_src,
+                                       int64_t Fin, int64_t Fout, int64_t ldo, int64_t members,
+                                       int64_t mstride_x, int64_t mstride_o, int relu,
+                                       int64_t union_max, gwen_stream_t stream_) {
+  if (N < 0 || N_src < 0 || members < 0 || ldo < Fout || union_max < 0 || union_max > kUCap)
+    return GWEN_EINVAL;
+  if (!gwen_gcn_wide_supported(Fin, Fout)) return GWEN_EINVAL;
+  if (N == 0 || members == 0) return GWEN_OK;
+  if (!t_rows || !t_lid || !t_val || !x || !W || !out || x == out) return GWEN_EINVAL;
+  if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || !gwen_aligned(W, 16) || mstride_x % 4 ||
+      ldo % 4 || mstride_o % 4 || (bias && !gwen_aligned(bias, 16)) || !gwen_aligned(t_val, 16) ||
+      !gwen_aligned(t_lid, 16))
+    return GWEN_EINVAL;
+  if (N_src * Fin * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;     // 32-bit row offsets
+  hipStream_t st = gwen_stream(stream_);
+  // unions of at most 128 rows leave room for a third stage buffer: two chunks of DMA in flight.
+  // 16 waves where the registers allow (Fin <= 128), 8 at Fin = 256 (W alone is 128 registers there).
+  const bool deep = union_max <= 128;
+#define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
+#define GWEN_W(FI, FO)                                                                                \
+  if (Fin == FI && Fout == FO)                                                                        \
+    return deep ? launch<FI, FO, (FI >= 256 ? 8 : 16), 2>(GWEN_ARGS)                                  \
+                : launch<FI, FO, (FI >= 256 ? 8 : 16), 1>(GWEN_ARGS)
+  GWEN_W(64, 64); GWEN_W(64, 128); GWEN_W(64, 256);
+  GWEN_W(128, 64); GWEN_W(128, 128); GWEN_W(128, 256);
+  GWEN_W(256, 64); GWEN_W(256, 128); GWEN_W(256, 256);
+#undef GWEN_W
+#undef GWEN_ARGS
+  return GWEN_EINVAL;
+}

@@ -138,6 +138,8 @@ class StackForward:
             for d in self.desc)
         self._scratch: Optional[Tensor] = None
         self._scratch_key = None
+        self._gd = None
+        self._gd_key = None
 
     def _scratch_for(self, members: int, dev) -> Tensor:
         key = (members, dev)
@@ -149,6 +151,31 @@ class StackForward:
             self._scratch = torch.empty(max(n, 4), dtype=torch.float32, device=dev)
             self._scratch_key = key
         return self._scratch
+
+    def _graph_desc(self, members: int) -> "_lib.GraphDesc":
+        """The views of the prepared graph the launcher may need (built on first use, kept with the graph):
+        grouped layout unless the K7 path is taken, tile layout when some AUTO layer would run as K8."""
+        g = self.graph
+        want_tiles = (not self._small) and any(
+            d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_wide_preferred(g.num_nodes, members, d.fin, d.fout)
+            for d in self.desc)
+        key = (members if want_tiles else 0, want_tiles)
+        if self._gd_key != key:
+            gr, gc, gv = (None, None, None) if self._small else g.grouped()
+            tiles = g.tiles() if want_tiles else None
+            gd = _lib.GraphDesc()
+            gd.N = g.num_nodes
+            gd.rowptr, gd.col, gd.val = g.rowptr.data_ptr(), g.col.data_ptr(), g.val.data_ptr()
+            gd.g_rowptr = 0 if gr is None else gr.data_ptr()
+            gd.g_col = 0 if gc is None else gc.data_ptr()
+            gd.g_val = 0 if gv is None else gv.data_ptr()
+            dense = g.dense()
+            gd.dense = 0 if dense is None else dense.data_ptr()
+            if tiles is not None:
+                gd.t_rows, gd.t_lid, gd.t_val = (t.data_ptr() for t in tiles[:3])
+                gd.union_max = tiles[3]
+            self._gd, self._gd_key = gd, key
+        return self._gd
 
     def run(self, x: Tensor, out: Optional[Tensor] = None,
             events: Optional[KernelEvents] = None) -> Tensor:
@@ -170,12 +197,10 @@ class StackForward:
         if out is None:
             out = torch.empty(*x.shape[:-1], self.fout, dtype=torch.float32, device=dev)
         scratch = self._scratch_for(members, dev)
-        g = self.graph
-        gr, gc, gv = (None, None, None) if self._small else g.grouped()
+        gd = self._graph_desc(members)
         with torch.cuda.device(dev):
             rc = _lib.lib().gwen_gnn_forward_f32(
-                _ptr(g.rowptr), _ptr(g.col), _ptr(g.val), _ptr(gr), _ptr(gc), _ptr(gv), _ptr(g.dense()), n,
-                self.desc, len(self.desc), _ptr(x),
+                C.byref(gd), self.desc, len(self.desc), _ptr(x),
                 _ptr(out), _ptr(scratch), scratch.numel(), members, _stream(dev),
                 None if events is None else events._ev,
                 None if events is None else events.info,

@@ -47,6 +47,7 @@ class GraphCSR:
     _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
     _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
     _dense: Optional[Tensor] = field(default=None, repr=False)
+    _tiles: Optional[tuple] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -66,6 +67,30 @@ class GraphCSR:
         if self._grouped is None:
             self._grouped = _grouped_impl(self)
         return self._grouped
+
+    def tiles(self) -> Optional[Tuple[Tensor, Tensor, Tensor, int]]:
+        """Tile layout for K8 (t_rows, t_lid, t_val, largest union): destination rows in tiles of 64 with the union of the
+        source rows each tile names (gwen_gcn_tiles64); None when the graph does not tile (a row with
+        more than 8 entries, or a tile naming more than 192 distinct rows).  Built on first use; one
+        flag read-back, once per graph."""
+        if self._tiles is None:
+            n, dev = self.num_nodes, self.device
+            L = _lib.lib()
+            t = int(L.gwen_gcn_tiles64_count(n))
+            if t == 0:
+                self._tiles = (None,)
+            else:
+                t_rows = torch.empty(t * 192, dtype=torch.int32, device=dev)
+                t_lid = torch.empty(t * 512, dtype=torch.int16, device=dev)
+                t_val = torch.empty(t * 512, dtype=torch.float32, device=dev)
+                st = torch.empty(2, dtype=torch.int32, device=dev)
+                with torch.cuda.device(dev):
+                    rc = L.gwen_gcn_tiles64(_ptr(self.rowptr), _ptr(self.col), _ptr(self.val), n,
+                                            _ptr(t_rows), _ptr(t_lid), _ptr(t_val), _ptr(st), _stream(dev))
+                _lib.check(rc, "gwen_gcn_tiles64")
+                flag, umax = (int(v) for v in st.tolist())
+                self._tiles = ((t_rows, t_lid, t_val, umax),) if flag == 0 else (None,)
+        return self._tiles[0]
 
     def dense(self) -> Optional[Tensor]:
         """The graph as a dense padded fp32 matrix for K7 (square graphs of at most 256 nodes: the

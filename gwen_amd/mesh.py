@@ -58,13 +58,54 @@ def _morton3(pos: np.ndarray, bits: int = 10) -> np.ndarray:
     return code
 
 
+def _hilbert2(order: int, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """Index of lattice point (x, y) on the 2-D Hilbert curve of the given order (vectorised xy -> d)."""
+    x = x.astype(np.int64).copy()
+    y = y.astype(np.int64).copy()
+    n = 1 << order
+    d = np.zeros_like(x)
+    s = n >> 1
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64)
+        ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        flat = ry == 0
+        flip = flat & (rx == 1)
+        x[flip] = n - 1 - x[flip]
+        y[flip] = n - 1 - y[flip]
+        xt = x[flat].copy()
+        x[flat] = y[flat]
+        y[flat] = xt
+        s >>= 1
+    return d
+
+
+def _cube_hilbert(pos: np.ndarray, order: int = 12) -> np.ndarray:
+    """Sort key: (cube face, Hilbert index of the equi-angular cube-sphere coordinates on that face).
+    Any run of consecutive nodes is a compact patch of the sphere -- 64 consecutive nodes of the nu = 100
+    mesh name at most 121 distinct neighbours (3-D Morton: up to 167), which is what K8's tiles want."""
+    n = pos.shape[0]
+    ax = np.argmax(np.abs(pos), axis=1)
+    rows = np.arange(n)
+    major = pos[rows, ax]
+    face = ax * 2 + (major < 0)
+    others = np.array([[1, 2], [0, 2], [0, 1]])
+    u = np.arctan(pos[rows, others[ax, 0]] / np.abs(major)) * (4.0 / np.pi)
+    v = np.arctan(pos[rows, others[ax, 1]] / np.abs(major)) * (4.0 / np.pi)
+    top = (1 << order) - 1
+    xi = np.clip(((u + 1.0) * 0.5 * top).round(), 0, top).astype(np.int64)
+    yi = np.clip(((v + 1.0) * 0.5 * top).round(), 0, top).astype(np.int64)
+    return face.astype(np.int64) * (1 << (2 * order)) + _hilbert2(order, xi, yi)
+
+
 def geodesic_mesh(nu: int, reorder: Optional[str] = None) -> Mesh:
     """Subdivide each icosahedron face into nu^2 triangles on an integer barycentric lattice.
 
     Shared corner/edge vertices are merged by integer lattice keys (never by float compare).
-    ``reorder``: None (generator order: corners, edge vertices, face interiors) or "morton"
-    (3-D Morton order of the projected points, a locality-preserving relabelling; the permutation
-    is kept in ``Mesh.perm``).
+    ``reorder``: None (generator order: corners, edge vertices, face interiors), "morton" (3-D Morton
+    order of the projected points) or "hilbert" (Hilbert curve on the faces of the cube-sphere: compact
+    patches, no long jumps); both are locality-preserving relabellings, the permutation is kept in
+    ``Mesh.perm``.
     """
     if nu < 1:
         raise ValueError("nu must be >= 1")
@@ -125,8 +166,8 @@ def geodesic_mesh(nu: int, reorder: Optional[str] = None) -> Mesh:
     faces = np.concatenate(tris, 0)
 
     perm = None
-    if reorder == "morton":
-        perm = np.argsort(_morton3(pos), kind="stable")
+    if reorder in ("morton", "hilbert"):
+        perm = np.argsort(_morton3(pos) if reorder == "morton" else _cube_hilbert(pos), kind="stable")
         inv = np.empty(n, dtype=np.int64)
         inv[perm] = np.arange(n)
         pos = pos[perm]

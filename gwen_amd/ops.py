@@ -121,6 +121,49 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     return out
 
 
+def wide_supported(fin: int, fout: int) -> bool:
+    return bool(_lib.lib().gwen_gcn_wide_supported(fin, fout))
+
+
+def wide_preferred(graph: GraphCSR, x: Tensor, fin: int, fout: int) -> bool:
+    """Would the stack launcher run this AUTO layer as K8?  (Same rule, so training and inference agree.)"""
+    m, n_src, _ = _rows2d(x)
+    if not _lib.lib().gwen_gcn_wide_preferred(graph.num_nodes, m, fin, fout):
+        return False
+    return graph.tiles() is not None
+
+
+def wide_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
+               relu: bool = False) -> Tensor:
+    """K8: act((A~ x) W^T + b) in one launch, tile-staged through LDS (widths in {64,128,256}, graphs
+    that tile: ``graph.tiles()``).  3xbf16 contraction; term for term K4's arithmetic."""
+    _require(x, "x")
+    _require(weight, "weight")
+    x = x.contiguous()
+    weight = weight.contiguous()
+    m, n_src, fin = _rows2d(x)
+    n = graph.num_nodes
+    fout = weight.size(0)
+    if n_src != graph.source_nodes or weight.size(1) != fin:
+        raise ValueError("shape mismatch between x, weight and the graph")
+    tiles = graph.tiles()
+    if tiles is None or not wide_supported(fin, fout):
+        raise ValueError("K8 needs a graph that tiles (rows of at most 8 entries, <= 192 distinct sources per "
+                         "64 rows) and widths in {64, 128, 256}")
+    if bias is not None:
+        _require(bias, "bias")
+        bias = bias.contiguous()
+    out = torch.empty(*x.shape[:-2], n, fout, dtype=torch.float32, device=x.device)
+    dev = x.device
+    t_rows, t_lid, t_val, umax = tiles
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_wide_layer_f32(
+            _ptr(t_rows), _ptr(t_lid), _ptr(t_val), _ptr(x), _ptr(weight), _ptr(bias), _ptr(out),
+            n, n_src, fin, fout, fout, m, n_src * fin, n * fout, int(relu), umax, _stream(dev))
+    _lib.check(rc, "gwen_gcn_wide_layer_f32")
+    return out
+
+
 def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
                 relu: bool = False, packed: Optional[Tensor] = None) -> Tensor:
     """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 256 nodes (dense adjacency).
@@ -231,12 +274,17 @@ class GCNLayerFunction(torch.autograd.Function):
         if order == "auto":
             if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout):
                 order = "small"              # K7: the reference's member graphs (<= 256 nodes)
+            elif wide_preferred(graph, x, fin, fout):
+                order = "wide"               # K8: K4's arithmetic, tile-staged (same backward)
             elif layer_supported(fin, fout):
                 order = "fused"
             else:
                 order = "aggregate_first" if fin < fout else "transform_first"
         if order == "small":
             out = small_layer(graph, x, weight, bias, relu, packed=packed)
+            saved_in = x
+        elif order == "wide":
+            out = wide_layer(graph, x, weight, bias, relu)
             saved_in = x
         elif order in ("fused", "fused_exact"):
             out = layer_fused(graph, x, weight, bias, relu, exact=(order == "fused_exact"))
@@ -263,7 +311,7 @@ class GCNLayerFunction(torch.autograd.Function):
             g = relu_backward(out, g)
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         gx = gw = None
-        if ctx.order in ("transform_first", "fused", "fused_exact", "small"):       # out = act(A~ x W^T + b) either way
+        if ctx.order in ("transform_first", "fused", "fused_exact", "small", "wide"):       # out = act(A~ x W^T + b) either way
             gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x

@@ -140,6 +140,47 @@ int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, const float *v
 int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
 
 /* ---------------------------------------------------------------------------------------------
+ * K8  K4's contract for WIDE layers on locality-ordered bounded-degree graphs (meshes), tile-staged:
+ *        out = act( (A~ x) W^T + bias )
+ * (the same piece of /root/reference/src/gwen/models_gnn.py:147-149,:204-206 as K4).  Destination rows
+ * are cut into tiles of GWEN_TILE_ROWS; per tile the UNION of the source rows its entries name is
+ * staged once in LDS by LDS-DMA, 64 features at a time, and the 7-8 gathers per destination row are
+ * served from there, overlapped with the 3xbf16 MFMA contraction of the previous chunk.
+ *
+ * gwen_gcn_tiles64 (part of K1, once per graph; plain CSR in -- rowptr/col/val of gwen_gcn_prep or
+ * gwen_gcn_prep_rect, every row at most 8 entries):
+ *   t_rows int32 [T * GWEN_TILE_UNION]  the tile's distinct source rows, ascending; a group of 4 slots that
+ *                                      starts past the union holds -1, other slots past it the first row
+ *   t_lid  u16   [T * 512]             per entry slot (row-in-tile * 8 + k) the rank of its source row in
+ *                                      the union; padding slots repeat the row's first entry
+ *   t_val  fp32  [T * 512]             per entry slot its weight, 0 for padding slots and rows >= N
+ *   status int32 [2]                   status[0] = 1 if some row has more than 8 entries or some tile's
+ *                                      union exceeds GWEN_TILE_UNION (K8 must not be used: K4 or K3 + K2
+ *                                      instead); status[1] = largest union.  T = gwen_gcn_tiles64_count(N).
+ * gwen_gcn_wide_layer_f32: x [members, N_src, Fin] contiguous rows, out [members, N, Fout] row stride ldo;
+ *   Fin, Fout in {64, 128, 256} (gwen_gcn_wide_supported); N_src * Fin * 4 < 2^32.  3xbf16 contraction,
+ *   fp32 accumulation; term for term the arithmetic of gwen_gcn_layer_f32(exact = 0).
+ *   union_max = status[1] of gwen_gcn_tiles64 (any upper bound <= GWEN_TILE_UNION is correct): with unions
+ *   of at most 128 rows the kernel keeps two chunks of DMA in flight instead of one.
+ * ------------------------------------------------------------------------------------------- */
+#define GWEN_TILE_ROWS 64
+#define GWEN_TILE_UNION 192
+int64_t gwen_gcn_tiles64_count(int64_t N);
+int gwen_gcn_tiles64(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+                     int32_t *t_rows, uint16_t *t_lid, float *t_val, int32_t *status,
+                     gwen_stream_t stream);
+int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout);
+/* 1 when an AUTO layer of these widths over N rows x members is issued as K8 rather than K4 (given a graph
+ * that tiles): every supported width pair with Fin >= 128 (measured 1.15x - 1.6x K4), and Fin = 64 once the
+ * layer's input no longer sits in the caches (members * N >= 300 000 rows; equal to K4 below that). */
+int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout);
+int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val,
+                            const float *x, const float *W, const float *bias, float *out, int64_t N,
+                            int64_t N_src, int64_t Fin, int64_t Fout, int64_t ldo, int64_t members,
+                            int64_t mstride_x, int64_t mstride_o, int relu, int64_t union_max,
+                            gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K5  K4 with the NEXT layer's projection chained on (A~ is linear, so a layer may be gathered at
  * min(Fin, Fout); for a shrinking layer its projection must exist before its gather starts):
  *   pre = 0:  out = act( (A~ x) W1^T + bias ) W2^T     x [.,Fin], W1 [F1,Fin], W2 [F2,F1], F2 < F1
@@ -163,10 +204,12 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
  *   layer's projection (K5) when that layer is AUTO too and shrinks, so that it is gathered at its
  *   narrow width -- otherwise transform-first (K3 then K2) when fout <= fin, aggregate-first (K2
  *   then K3) when fin < fout.  Explicit orders are taken literally, layer by layer.
- * rowptr/col/val: the prepared CSR (K2 layers); g_rowptr/g_col/g_val: its grouped form (K4/K5 layers;
- *   g_col/g_val may be NULL when no layer resolves to K4/K5, g_rowptr NULL = uniform layout).
- * dense: the graph as a dense padded matrix (gwen_gcn_dense_f32) or NULL; when given and every
- *   layer is AUTO and gwen_gcn_small_supported(N, fin, fout), every layer is ONE K7 launch.
+ * graph (HOST struct of device pointers): rowptr/col/val = the prepared CSR (K2 layers); g_rowptr/g_col/g_val
+ *   = its grouped form (K4/K5 layers; g_col/g_val may be NULL when no layer resolves to K4/K5, g_rowptr
+ *   NULL = uniform layout); dense = the graph as a dense padded matrix (gwen_gcn_dense_f32) or NULL -- when
+ *   given and every layer is AUTO and gwen_gcn_small_supported(N, fin, fout), every layer is ONE K7 launch;
+ *   t_rows/t_lid/t_val/union_max = the tile layout of gwen_gcn_tiles64 or NULL -- when given, AUTO layers
+ *   with gwen_gcn_wide_preferred() run as K8.
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
  * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
  * events (HOST array of hipEvent_t, or NULL): if given, events[2i] / events[2i+1] are recorded on
@@ -183,6 +226,20 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
 #define GWEN_KIND_LAYER 4       /* K4 */
 #define GWEN_KIND_CHAIN 5       /* K5: info.fin = gathered width, info.fout = stored width */
 #define GWEN_KIND_SMALL 6       /* K7: whole layer on a small graph (dense adjacency) */
+#define GWEN_KIND_WIDE 8        /* K8: whole layer, tile-staged */
+
+typedef struct gwen_graph {
+  int64_t N;                          /* nodes (rows of x and out) */
+  const int32_t *rowptr, *col;        /* gwen_gcn_prep */
+  const float *val;
+  const int32_t *g_rowptr, *g_col;    /* gwen_gcn_group8 (g_rowptr NULL = uniform) or NULL */
+  const float *g_val;
+  const float *dense;                 /* gwen_gcn_dense_f32 or NULL */
+  const int32_t *t_rows;              /* gwen_gcn_tiles64 or NULL */
+  const uint16_t *t_lid;
+  const float *t_val;
+  int64_t union_max;
+} gwen_graph;
 
 typedef struct gwen_layer_desc {
   const float *W;
@@ -197,13 +254,10 @@ typedef struct gwen_launch_info {
 
 int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members, const gwen_layer_desc *layers,
                                         int32_t n_layers);
-int gwen_gnn_forward_f32(const int32_t *rowptr, const int32_t *col, const float *val,
-                         const int32_t *g_rowptr, const int32_t *g_col, const float *g_val,
-                         const float *dense, int64_t N, const gwen_layer_desc *layers,
-                         int32_t n_layers, const float *x, float *out,
-                         float *scratch, int64_t scratch_floats, int64_t members,
-                         gwen_stream_t stream, void **events, gwen_launch_info *info,
-                         int32_t max_launches, int32_t *n_launches);
+int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_desc *layers, int32_t n_layers,
+                         const float *x, float *out, float *scratch, int64_t scratch_floats,
+                         int64_t members, gwen_stream_t stream, void **events,
+                         gwen_launch_info *info, int32_t max_launches, int32_t *n_launches);
 
 /* ---------------------------------------------------------------------------------------------
  * K7  a whole GCNConv layer on a SMALL graph (N <= 256) with wide features -- the reference's own

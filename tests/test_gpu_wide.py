@@ -1,0 +1,172 @@
+"""K8 (tile-staged wide layer, csrc/wide.hip) and its tile prep (csrc/tiles.hip) on the device.
+
+Checked against: a numpy restatement of the tile layout, K4 bit for bit (K8 is K4's 3xbf16 arithmetic term
+for term), the C oracle (oracle/gcn_ref.c, fp64) within tolerance, and at config size (nu = 100, 256
+channels, 4 members) through linearity / determinism / member independence plus the oracle on one member.
+The layer being replaced: torch-geometric GCNConv.forward as called at
+/root/reference/src/gwen/models_gnn.py:147-149,:204-206."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import REL_TOL, SEED, make_params, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ga(hip_lib):
+    import gwen_amd
+    return gwen_amd
+
+
+def _mesh_graph(ga, nu, reorder="morton"):
+    m = ga.geodesic_mesh(nu, reorder=reorder)
+    ei = torch.from_numpy(m.edge_index)
+    return m, ei, ga.prepare_graph(ei.to(DEV), m.num_nodes)
+
+
+@pytest.mark.parametrize("nu,reorder", [(4, None), (10, "morton"), (30, "morton"), (30, "hilbert"), (30, None)])
+def test_tile_layout_matches_numpy(ga, nu, reorder):
+    m, ei, g = _mesh_graph(ga, nu, reorder)
+    tiles = g.tiles()
+    if reorder is None and nu >= 30:
+        assert tiles is None       # generator order has no locality: 64 rows name > 192 distinct sources
+        return
+    assert tiles is not None
+    t_rows, t_lid, t_val = (t.cpu().numpy() for t in tiles[:3])
+    umax = 0
+    t_lid = t_lid.view(np.uint16)
+    n = m.num_nodes
+    rowptr, col, val = g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy()
+    T = (n + 63) // 64
+    assert t_rows.shape == (T * 192,) and t_lid.shape == (T * 512,) and t_val.shape == (T * 512,)
+    for t in range(T):
+        ent_c = np.full(512, -1, dtype=np.int64)
+        ent_w = np.zeros(512, dtype=np.float32)
+        for lr in range(64):
+            r = t * 64 + lr
+            if r >= n:
+                continue
+            a, b = rowptr[r], rowptr[r + 1]
+            assert b - a <= 8
+            ent_c[lr * 8: lr * 8 + b - a] = col[a:b]
+            ent_w[lr * 8: lr * 8 + b - a] = val[a:b]
+        uniq = np.unique(ent_c[ent_c >= 0])
+        nu_ = len(uniq)
+        assert nu_ <= 192
+        umax = max(umax, nu_)
+        slots = t_rows[t * 192:(t + 1) * 192]
+        assert np.array_equal(slots[:nu_], uniq)
+        for k in range(nu_, 192):
+            assert slots[k] == (uniq[0] if (k & ~3) < nu_ else -1)
+        assert np.array_equal(t_val[t * 512:(t + 1) * 512], ent_w)
+        lid = t_lid[t * 512:(t + 1) * 512].astype(np.int64)
+        for s in range(512):
+            c = ent_c[s] if ent_c[s] >= 0 else ent_c[s & ~7]
+            if c >= 0:
+                assert uniq[lid[s]] == c
+            else:
+                assert lid[s] == 0
+    assert tiles[3] == umax
+
+
+def test_untileable_graphs_report_none(ga):
+    ei = torch.from_numpy(ga.complete_graph(40)).to(DEV)            # rows of 40 entries
+    assert ga.prepare_graph(ei, 40).tiles() is None
+    # bounded degree but no locality: 64 rows name ~448 distinct sources
+    g = torch.Generator().manual_seed(SEED)
+    n = 20000
+    src = torch.randint(0, n, (6 * n,), generator=g)
+    dst = torch.arange(n).repeat(6)
+    assert ga.prepare_graph(torch.stack([src, dst]).to(DEV), n).tiles() is None
+    with pytest.raises(ValueError):
+        from gwen_amd import ops
+        ops.wide_layer(ga.prepare_graph(ei, 40), torch.zeros(40, 64, device=DEV), torch.zeros(64, 64, device=DEV))
+
+
+@pytest.mark.parametrize("fin,fout", [(64, 64), (64, 128), (64, 256), (128, 64), (128, 128), (128, 256),
+                                      (256, 64), (256, 128), (256, 256)])
+@pytest.mark.parametrize("nu,reorder", [(4, "morton"), (13, "morton"), (13, "hilbert")])
+def test_wide_equals_k4_bitwise_and_oracle(ga, cref, fin, fout, nu, reorder):
+    """morton at nu = 13 has unions above 128 (one chunk of DMA in flight), hilbert stays below (two)."""
+    from gwen_amd import ops
+    m, ei, g = _mesh_graph(ga, nu, reorder)
+    n = m.num_nodes
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(SEED + fin))
+    w, b = make_params(fin, fout)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    for relu in (False, True):
+        got = ops.wide_layer(g, xd, wd, bd, relu=relu)
+        k4 = ops.layer_fused(g, xd, wd, bd, relu=relu, exact=False)
+        assert torch.equal(got, k4), (fin, fout, relu)
+        ref = cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=relu, f64=True)
+        assert rel_err(got, ref) <= 2e-5
+    assert torch.equal(ops.wide_layer(g, xd, wd, None), ops.layer_fused(g, xd, wd, None))
+
+
+def test_wide_members_axis_and_few_tiles(ga, cref):
+    """[members, N, F] shares one tile layout; fewer tiles than CUs and more tiles than CUs."""
+    from gwen_amd import ops
+    for nu, members, reorder in ((3, 3, "morton"), (20, 5, "morton"), (20, 3, "hilbert")):
+        m, ei, g = _mesh_graph(ga, nu, reorder)
+        n = m.num_nodes
+        x = torch.randn(members, n, 128, generator=torch.Generator().manual_seed(SEED))
+        w, b = make_params(128, 128)
+        got = ops.wide_layer(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+        for k in range(members):
+            one = ops.wide_layer(g, x[k].to(DEV), w.to(DEV), b.to(DEV), relu=True)
+            assert torch.equal(got[k], one)
+        ref = cref.conv(x[members - 1].numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True)
+        assert rel_err(got[members - 1], ref) <= 2e-5
+
+
+def test_wide_bipartite(ga):
+    """Rectangular graphs (grid -> mesh maps of SURVEY 8(f) f2) tile the same way: x has N_src rows."""
+    from gwen_amd import ops
+    from gwen_amd.g2m import grid_mesh_edges
+    from gwen_amd.graph import prepare_bipartite
+    m = ga.geodesic_mesh(12, reorder="morton")
+    g2m_e, m2g_e = grid_mesh_edges(m)
+    n_mesh, n_grid = m.num_nodes, m.faces.shape[0]
+    g2m = prepare_bipartite(torch.from_numpy(g2m_e).to(DEV), n_grid, n_mesh)
+    m2g = prepare_bipartite(torch.from_numpy(m2g_e).to(DEV), n_mesh, n_grid)
+    tiled = 0
+    for g, n_src in ((g2m, n_grid), (m2g, n_mesh)):
+        if g.tiles() is None:
+            continue
+        tiled += 1
+        x = torch.randn(n_src, 64, device=DEV)
+        w, b = make_params(64, 128)
+        got = ops.wide_layer(g, x, w.to(DEV), b.to(DEV), relu=True)
+        assert torch.equal(got, ops.layer_fused(g, x, w.to(DEV), b.to(DEV), relu=True))
+    assert tiled >= 1
+
+
+def test_c3_layer_at_config_size_four_members(ga, cref):
+    """BASELINE c3 / c5 per-GPU load: nu = 100 (N = 100 002, E = 600 000), 256 -> 256, 4 members (the
+    HBM-bound leg of bench.py).  One member against the C oracle (fp64); all members through determinism,
+    K4 equality and linearity in x."""
+    from gwen_amd import ops
+    m, ei, g = _mesh_graph(ga, 100, "hilbert")
+    n = m.num_nodes
+    assert (n, m.num_edges) == (100002, 600000) and g.tiles()[3] <= 128
+    members = 4
+    gen = torch.Generator().manual_seed(SEED)
+    x = torch.randn(members, n, 256, generator=gen)
+    w, b = make_params(256, 256)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    got = ops.wide_layer(g, xd, wd, bd, relu=True)
+    assert torch.equal(got, ops.wide_layer(g, xd, wd, bd, relu=True))
+    assert torch.equal(got, ops.layer_fused(g, xd, wd, bd, relu=True))
+    ref = cref.conv(x[2].numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True)
+    assert rel_err(got[2], ref) <= 2e-5
+    # per-row check as well: no row may hide behind the tensor's largest value
+    diff = (got[2].cpu().double() - torch.from_numpy(ref)).abs().amax(1)
+    scale = torch.from_numpy(ref).abs().amax(1).clamp_min(1e-3)
+    assert float((diff / scale).max()) <= 1e-3
+    # linearity (no bias, no ReLU): f(x0 + 2 x1) = f(x0) + 2 f(x1)
+    lin = ops.wide_layer(g, xd[0] + 2 * xd[1], wd, None)
+    parts = ops.wide_layer(g, xd[0], wd, None) + 2 * ops.wide_layer(g, xd[1], wd, None)
+    assert rel_err(lin, parts) <= 2e-5

@@ -31,15 +31,27 @@ def test_geodesic_mesh_counts_and_conventions(nu):
     assert n - e // 2 + len(m.faces) == 2
 
 
-def test_c2_mesh_size_and_morton_relabelling_is_isomorphic():
+@pytest.mark.parametrize("reorder", ["morton", "hilbert"])
+def test_c2_mesh_size_and_relabelling_is_isomorphic(reorder):
     m = gwen_amd.geodesic_mesh(100)
     assert (m.num_nodes, m.num_edges) == (100002, 600000)
-    a, b = gwen_amd.geodesic_mesh(6), gwen_amd.geodesic_mesh(6, reorder="morton")
+    a, b = gwen_amd.geodesic_mesh(6), gwen_amd.geodesic_mesh(6, reorder=reorder)
     inv = np.empty_like(b.perm); inv[b.perm] = np.arange(len(inv))
     ea = inv[a.edge_index]
     ka = np.sort(ea[0] * a.num_nodes + ea[1]); kb = b.edge_index[0] * b.num_nodes + b.edge_index[1]
     assert np.array_equal(ka, kb)
     assert np.allclose(a.pos[b.perm], b.pos)
+
+
+def test_hilbert_order_keeps_tile_unions_small():
+    """What K8 needs of the node order (csrc/tiles.hip): 64 consecutive destination rows of the nu = 100
+    mesh name at most 128 distinct source rows (self-loops included) under the Hilbert relabelling."""
+    m = gwen_amd.geodesic_mesh(100, reorder="hilbert")
+    n = m.num_nodes
+    src = np.concatenate([m.edge_index[0], np.arange(n)])
+    dst = np.concatenate([m.edge_index[1], np.arange(n)])
+    cnt = np.bincount(np.unique((dst // 64) * n + src) // n)
+    assert cnt.max() <= 128 and cnt.mean() < 110
 
 
 def test_complete_graph_matches_reference_producer_conventions():
