@@ -4,9 +4,10 @@ The reference recomputes ``gcn_norm`` inside each of the six ``GCNConv`` calls o
 (/root/reference/src/gwen/models_gnn.py:147-149,:204-206; constructors :118-184 leave
 ``cached=False``) although normalisation depends on topology only.  Here the result is a
 ``GraphCSR`` that every layer of a forward shares, cached on the *identity* of the ``edge_index``
-tensor object (weak reference + in-place version counter): a new tensor object -- e.g. each
-relabelled NeighborLoader batch of the reference's loops, models_gnn.py:351-360 -- is a miss even
-when the caching allocator hands back the same address, so a stale CSR can never be used.
+tensor object (weak reference + in-place version counter) and, for tensors not seen before, on their
+*content* (a 128-bit device-side checksum): each NeighborLoader batch of the reference's loops
+(models_gnn.py:351-360) is a new tensor object, usually with the same edges -- a content hit -- and a
+relabelled batch has different bytes, so a stale CSR can never be used.
 """
 from __future__ import annotations
 
@@ -157,15 +158,7 @@ def _alloc_workspace(n: int, e: int, device: torch.device) -> Tensor:
     return torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=device)
 
 
-def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor] = None, *,
-                  add_self_loops: bool = True, improved: bool = False, normalize: bool = True,
-                  validate: bool = True) -> GraphCSR:
-    """Run K1 on the device holding ``edge_index`` (current stream) and return the CSR.
-
-    ``validate=True`` reads back one flag (a stream synchronisation) and raises ``IndexError`` when a
-    node index lies outside ``[0, num_nodes)`` -- what the reference's CPU path raises from
-    ``index_select``.  Pass ``validate=False`` to stay asynchronous (bad edges are then dropped).
-    """
+def _check_edge_index(edge_index, num_nodes: int) -> None:
     if not isinstance(edge_index, Tensor):
         raise TypeError("edge_index must be a torch.Tensor")
     if edge_index.dtype != torch.int64:
@@ -176,6 +169,18 @@ def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tens
         raise RuntimeError("gwen_amd needs edge_index on a HIP device; there is no CPU fallback")
     if num_nodes < 0:
         raise ValueError("num_nodes must be >= 0")
+
+
+def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor] = None, *,
+                  add_self_loops: bool = True, improved: bool = False, normalize: bool = True,
+                  validate: bool = True) -> GraphCSR:
+    """Run K1 on the device holding ``edge_index`` (current stream) and return the CSR.
+
+    ``validate=True`` reads back one flag (a stream synchronisation) and raises ``IndexError`` when a
+    node index lies outside ``[0, num_nodes)`` -- what the reference's CPU path raises from
+    ``index_select``.  Pass ``validate=False`` to stay asynchronous (bad edges are then dropped).
+    """
+    _check_edge_index(edge_index, num_nodes)
     dev = edge_index.device
     ei = edge_index.contiguous()
     e = ei.size(1)
@@ -205,7 +210,8 @@ def prepare_graph(edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tens
             _ptr(rowptr), _ptr(col), _ptr(val), _ptr(eid), _ptr(dis), _ptr(status), _ptr(ws),
             ws.numel(), _stream(dev))
     _lib.check(rc, "gwen_gcn_prep")
-    g = GraphCSR(n, e, rowptr, col, val, eid, dis, status, _workspace=ws)
+    # the sort workspace (16 B x (N + E)) is not kept: transposed() / grouped() allocate their own on demand
+    g = GraphCSR(n, e, rowptr, col, val, eid, dis, status)
     if validate and int(status[0].item()) != 0:
         raise IndexError(f"edge_index holds node indices outside [0, {n})")
     return g
@@ -238,50 +244,108 @@ def prepare_bipartite(edge_index: Tensor, num_src: int, num_dst: int,
                                            _ptr(rowptr), _ptr(col), _ptr(val), _ptr(eid), _ptr(status),
                                            _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gwen_gcn_prep_rect")
-    g = GraphCSR(num_dst, e, rowptr, col, val, eid, torch.empty(1, device=dev), status, num_src=num_src,
-                 _workspace=ws)
+    g = GraphCSR(num_dst, e, rowptr, col, val, eid, torch.empty(1, device=dev), status, num_src=num_src)
     if validate and int(status[0].item()) != 0:
         raise IndexError("edge_index holds node indices outside the source / target ranges")
     return g
 
 
+def _version_of(t: Tensor):
+    """In-place version counter, or None for tensors that do not track one (created under
+    ``torch.inference_mode()``): those are never trusted by identity, only by content."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def content_key(t: Tensor) -> Tuple[int, int]:
+    """128-bit content checksum of a device tensor (gwen_checksum128): one small launch pair and a 16-byte
+    read-back (a stream synchronisation -- the reference's loops synchronise per batch anyway:
+    ``.to(device)`` of a pageable tensor at models_gnn.py:358-360, ``loss.item()`` at :447)."""
+    t = t.contiguous()
+    dev = t.device
+    L = _lib.lib()
+    ws = torch.empty(int(L.gwen_checksum_workspace_bytes()), dtype=torch.uint8, device=dev)
+    out = torch.empty(2, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.gwen_checksum128(_ptr(t), t.numel() * t.element_size(), _ptr(out), _ptr(ws), ws.numel(),
+                                _stream(dev))
+    _lib.check(rc, "gwen_checksum128")
+    a, b = out.tolist()
+    return a, b
+
+
 class GraphCache:
-    """Small LRU of prepared graphs keyed on tensor identity (see module docstring)."""
+    """Prepared graphs, found by tensor identity first and by CONTENT second.
+
+    Identity (weak reference + in-place version counter) costs nothing and covers callers that keep one
+    ``edge_index`` tensor.  The reference's loops do not: every NeighborLoader batch is a new tensor
+    (models_gnn.py:351-360, :434-443) -- on its complete member graph with the same edges each time -- so a
+    tensor unknown by identity is looked up by a 128-bit checksum of its bytes (``content_key``); a hit
+    re-uses the prepared graph and skips K1 and every derived layout.  A relabelled batch has different
+    bytes and therefore never hits a stale graph.  Entries of dead tensors are dropped by their weak
+    reference's callback; the content table is a small LRU.
+    """
 
     def __init__(self, capacity: int = 8):
         self.capacity = capacity
-        self._d: "OrderedDict[tuple, tuple]" = OrderedDict()
-        self.hits = 0
+        self._by_id: dict = {}                                  # id(edge_index) -> (refs, versions, opts, graph)
+        self._by_content: "OrderedDict[tuple, GraphCSR]" = OrderedDict()
+        self.hits = 0                                           # identity hits
+        self.content_hits = 0
         self.misses = 0
+
+    _check = staticmethod(_check_edge_index)
+
+    def _forget(self, key: int) -> None:
+        self._by_id.pop(key, None)
 
     def get(self, edge_index: Tensor, num_nodes: int, edge_weight: Optional[Tensor], *,
             add_self_loops: bool, improved: bool, normalize: bool) -> GraphCSR:
-        key = (id(edge_index), num_nodes, None if edge_weight is None else id(edge_weight),
-               add_self_loops, improved, normalize)
-        ent = self._d.get(key)
+        opts = (num_nodes, add_self_loops, improved, normalize)
+        ent = self._by_id.get(id(edge_index))
         if ent is not None:
-            ei_ref, ei_ver, ew_ref, ew_ver, g = ent
-            same = ei_ref() is edge_index and ei_ver == edge_index._version
+            ei_ref, ei_ver, ew_ref, ew_ver, e_opts, g = ent
+            same = ei_ref() is edge_index and ei_ver is not None and ei_ver == _version_of(edge_index) \
+                and e_opts == opts
             if edge_weight is not None:
                 same = same and ew_ref is not None and ew_ref() is edge_weight \
-                    and ew_ver == edge_weight._version
+                    and ew_ver is not None and ew_ver == _version_of(edge_weight)
+            else:
+                same = same and ew_ref is None
             if same:
-                self._d.move_to_end(key)
                 self.hits += 1
                 return g
-            del self._d[key]
-        self.misses += 1
-        g = prepare_graph(edge_index, num_nodes, edge_weight, add_self_loops=add_self_loops,
-                          improved=improved, normalize=normalize)
-        self._d[key] = (weakref.ref(edge_index), edge_index._version,
-                        None if edge_weight is None else weakref.ref(edge_weight),
-                        None if edge_weight is None else edge_weight._version, g)
-        while len(self._d) > self.capacity:
-            self._d.popitem(last=False)
+            del self._by_id[id(edge_index)]
+        # unknown (or modified) tensor: by content
+        self._check(edge_index, num_nodes)
+        key = (tuple(edge_index.shape), opts, content_key(edge_index),
+               None if edge_weight is None else content_key(edge_weight.detach().to(torch.float32)))
+        g = self._by_content.get(key)
+        if g is not None:
+            self._by_content.move_to_end(key)
+            self.content_hits += 1
+        else:
+            self.misses += 1
+            g = prepare_graph(edge_index, num_nodes, edge_weight, add_self_loops=add_self_loops,
+                              improved=improved, normalize=normalize)
+            self._by_content[key] = g
+            while len(self._by_content) > self.capacity:
+                self._by_content.popitem(last=False)
+        ident = id(edge_index)
+        try:
+            ei_ref = weakref.ref(edge_index, lambda _r, k=ident: self._forget(k))
+            ew_ref = None if edge_weight is None else weakref.ref(edge_weight)
+        except TypeError:
+            return g
+        self._by_id[ident] = (ei_ref, _version_of(edge_index), ew_ref,
+                              None if edge_weight is None else _version_of(edge_weight), opts, g)
         return g
 
     def clear(self) -> None:
-        self._d.clear()
+        self._by_id.clear()
+        self._by_content.clear()
 
 
 _default_cache = GraphCache()

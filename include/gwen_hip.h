@@ -89,6 +89,15 @@ int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const float *val,
                     int64_t cap, int32_t *g_rowptr, int32_t *g_col, float *g_val, int32_t *uniform,
                     void *workspace, size_t workspace_bytes, gwen_stream_t stream);
 
+/* Content checksum of a device buffer (128 bits: two independent position-dependent 64-bit sums over its
+ * 8-byte words), the key under which a caller caches prepared graphs: the reference's loaders hand every
+ * forward a NEW edge_index tensor with the same edges (/root/reference/src/gwen/models_gnn.py:351-360).
+ * data: 8-byte aligned; out: uint64 [2] (device); workspace: gwen_checksum_workspace_bytes() bytes.
+ * Deterministic; two small launches; nothing is read back here. */
+int64_t gwen_checksum_workspace_bytes(void);
+int gwen_checksum128(const void *data, int64_t bytes, uint64_t *out, void *workspace,
+                     int64_t workspace_bytes, gwen_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  fused propagate == MessagePassing.propagate (message w~ * x_j, aggregate add at target)
  *     + bias add (GCNConv.forward) + torch.relu (/root/reference/src/gwen/models_gnn.py:147-149,

@@ -130,3 +130,51 @@ def test_c3_processor_stack_vs_oracle(F, steps):
     g = gwen_amd.prepare_graph(ei.to(DEV), mesh.num_nodes)
     plan = gwen_amd.StackForward([(w.to(DEV), b.to(DEV), True, "auto") for w, b in zip(ws, bs)], g)
     assert rel_err(plan.run(x.to(DEV)), want) <= REL_TOL
+
+
+def test_checksum_is_a_function_of_the_bytes(ga):
+    """gwen_checksum128: equal bytes -> equal key (whatever the tensor object), any changed byte, a swapped
+    pair of words or a different length -> another key; ragged byte counts and empty buffers included."""
+    from gwen_amd.graph import content_key
+    g = torch.Generator().manual_seed(SEED)
+    for n in (0, 1, 7, 4096, 1_200_001):
+        a = torch.randint(-2 ** 40, 2 ** 40, (n,), generator=g).to(DEV)
+        k = content_key(a)
+        assert content_key(a.clone()) == k and content_key(a) == k
+        if n >= 2:
+            b = a.clone(); b[n // 2] += 1
+            assert content_key(b) != k
+            c = a.clone(); c[0], c[n - 1] = a[n - 1], a[0]
+            if not torch.equal(c, a):
+                assert content_key(c) != k                      # position-dependent
+            assert content_key(a[:-1]) != k
+    u8 = torch.arange(13, dtype=torch.uint8, device=DEV)        # 13 bytes: one word + a 5-byte tail
+    k8 = content_key(u8)
+    v8 = u8.clone(); v8[12] = 99
+    assert content_key(u8.clone()) == k8 and content_key(v8) != k8
+
+
+def test_fresh_edge_index_tensors_hit_the_cache_by_content(ga):
+    """The reference's loops hand every forward a new edge_index tensor with the same edges
+    (models_gnn.py:351-360): K1 runs once, relabelled edges run it again, results are unchanged."""
+    n = 125
+    ei_host = torch.from_numpy(ga.complete_graph(n))
+    conv = ga.GCNConv(32, 16).to(DEV)
+    x = torch.randn(n, 32, device=DEV)
+    cache = ga.default_cache()
+    cache.clear()
+    m0, c0 = cache.misses, cache.content_hits
+    with torch.no_grad():
+        y0 = conv(x, ei_host.to(DEV))
+        for _ in range(3):
+            assert torch.equal(conv(x, ei_host.to(DEV)), y0)
+    assert (cache.misses - m0, cache.content_hits - c0) == (1, 3)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(SEED))
+    relabelled = perm[ei_host]                                    # same graph family, different bytes
+    with torch.no_grad():
+        y1 = conv(x[torch.argsort(perm)], relabelled.to(DEV))
+    assert cache.misses - m0 == 2
+    assert rel_err(y1[perm], y0) <= 1e-5                          # K_N relabelled is K_N: same rows, permuted
+    with torch.inference_mode():
+        ei_inf = ei_host.to(DEV)
+        assert torch.equal(conv(x, ei_inf), y0) and cache.misses - m0 == 2

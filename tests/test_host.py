@@ -137,30 +137,56 @@ def test_cpu_tensors_raise_runtime_error_not_fallback():
         conv(np.zeros((3, 8)), ei)
 
 
-def test_graph_cache_keys_on_tensor_identity(monkeypatch):
+def test_graph_cache_identity_then_content(monkeypatch):
+    """Identity first (free), content second (128-bit checksum): a NEW tensor with the same edges -- what
+    every NeighborLoader batch of the reference is (models_gnn.py:351-360) -- re-uses the prepared graph;
+    different bytes, options or an in-place edit never do.  (CPU stand-ins for K1 and the checksum.)"""
     calls = []
     monkeypatch.setattr(G, "prepare_graph", lambda ei, n, ew=None, **kw: calls.append((id(ei), n, kw)) or object())
+    monkeypatch.setattr(G, "content_key", lambda t: (hash(t.numpy().tobytes()), tuple(t.shape).__hash__()))
+    monkeypatch.setattr(G.GraphCache, "_check", staticmethod(lambda ei, n: None))
     cache = G.GraphCache(capacity=2)
     opts = dict(add_self_loops=True, improved=False, normalize=True)
     a = torch.tensor([[0, 1], [1, 0]])
     g1 = cache.get(a, 2, None, **opts)
-    assert cache.get(a, 2, None, **opts) is g1 and len(calls) == 1        # same object: hit
+    assert cache.get(a, 2, None, **opts) is g1 and len(calls) == 1        # same object: identity hit
+    assert (cache.hits, cache.content_hits, cache.misses) == (1, 0, 1)
     b = a.clone()
-    assert cache.get(b, 2, None, **opts) is not g1 and len(calls) == 2    # equal content, new object: miss
+    assert cache.get(b, 2, None, **opts) is g1 and len(calls) == 1        # equal content, new object: content hit
+    assert cache.content_hits == 1
+    assert cache.get(b, 2, None, **opts) is g1 and cache.hits == 2        # ... and known by identity from now on
     a[0, 0] = 1                                                           # in-place edit bumps _version
-    assert cache.get(a, 2, None, **opts) is not g1 and len(calls) == 3
-    assert cache.get(a, 3, None, **opts) is not None and len(calls) == 4  # other num_nodes
+    assert cache.get(a, 2, None, **opts) is not g1 and len(calls) == 2    # other bytes: miss
+    assert cache.get(a, 3, None, **opts) is not None and len(calls) == 3  # other num_nodes: miss
     w = torch.ones(2)
-    cache.get(a, 2, w, **opts); cache.get(a, 2, w, **opts)
-    assert len(calls) == 5
-    assert len(cache._d) <= 2                                             # LRU bound
-    # a dead tensor whose id is reused must not hit
-    c = torch.tensor([[0], [1]]); cache.get(c, 2, None, **opts); key_id = id(c); del c
+    gw = cache.get(a, 2, w, **opts)
+    assert cache.get(a, 2, w, **opts) is gw and len(calls) == 4
+    assert cache.get(a, 2, w.clone(), **opts) is gw and len(calls) == 4   # equal weights by content
+    assert cache.get(a, 2, 2 * w, **opts) is not gw and len(calls) == 5
+    assert len(cache._by_content) <= 2                                    # LRU bound
+    # a dead tensor's identity entry disappears with it (weakref callback); its id may be reused safely
+    c = torch.tensor([[0], [1]]); cache.get(c, 2, None, **opts); key_id = id(c)
+    assert key_id in cache._by_id
+    del c
+    assert key_id not in cache._by_id
     n_before = len(calls)
     d = torch.tensor([[1], [0]])
     cache.get(d, 2, None, **opts)
     assert len(calls) == n_before + 1
 
+
+def test_graph_cache_handles_inference_mode_tensors(monkeypatch):
+    """Tensors created under torch.inference_mode() have no version counter: never trusted by identity."""
+    calls = []
+    monkeypatch.setattr(G, "prepare_graph", lambda ei, n, ew=None, **kw: calls.append(1) or object())
+    monkeypatch.setattr(G, "content_key", lambda t: (hash(t.numpy().tobytes()), 0))
+    monkeypatch.setattr(G.GraphCache, "_check", staticmethod(lambda ei, n: None))
+    cache = G.GraphCache()
+    opts = dict(add_self_loops=True, improved=False, normalize=True)
+    with torch.inference_mode():
+        a = torch.tensor([[0, 1], [1, 0]])
+        g1 = cache.get(a, 2, None, **opts)
+        assert cache.get(a, 2, None, **opts) is g1 and len(calls) == 1 and cache.hits == 0 and cache.content_hits == 1
 
 def test_member_range_partitions_every_member_once():
     for members in (0, 1, 7, 8, 32, 33):

@@ -16,15 +16,12 @@
 //   * contracts the 64 x 64 chunk with W on the matrix cores (3xbf16, fp32 accumulate, as K4) while the
 //     DMA of the chunk after next is in flight and the next chunk is being aggregated;
 //   * adds bias / ReLU and stores after the last chunk.
-// One block per CU (16 waves; 8 at Fin = 256, where W alone takes 128 registers per wave) walks its tiles
-// persistently; ONE barrier per 64-feature chunk ("step"):
-//     [scalar loads of the row ids of chunk s+D+1]
-//     s_waitcnt vmcnt(n): DMA of chunk s+1 landed;  barrier
-//     2 x (row tiles per wave) regions, each: a share of the step's memory instructions -- the DMAs of chunk
-//     s+D+1 -> stage[s % (D+1)] and the stores of the tile finished in step s-1 --, the LDS reads of a share of
-//     aggregate(s+1), one (row tile, k-step) unit of mfma(s), that share's VALU work woven behind the MFMAs.
-// D = 2 chunks of DMA in flight when the graph's unions stay within 128 rows (three 32 KB stage buffers:
-// the cube-sphere Hilbert node order keeps the nu = 100 mesh at <= 121), D = 1 up to 192 rows (two 48 KB buffers).
+// One 8-wave block per CU walks its tiles persistently; ONE barrier per 64-feature chunk:
+//     top(s):  s_waitcnt vmcnt(0) (DMA of chunk s+1 landed), barrier
+//              [stores of the tile that finished in chunk s-1]
+//              issue DMA(s+2) -> stage[s % 2]          (free: aggregate(s) is behind the barrier)
+//              aggregate(s+1): stage[(s+1) % 2] -> A[(s+1) % 2]
+//              mfma(s):        A[s % 2] x W[:, chunk]  -> accumulators
 // The DMAs are issued by inline asm, so hipcc neither counts nor drains them (cdna_hip_programming.md
 // section 5 "Pipelining across barriers"); every other global read of the loop is a scalar load (the union
 // rows of the tile) and the only vector-memory instructions hipcc sees are the output stores.
@@ -33,7 +30,7 @@
 // that XCD's L2.
 // Numerics: identical to K4's 3xbf16 path term for term (same aggregation order, same split, same MFMA
 // sequence) -- tests compare the two bitwise.
-#include "common.h"
+#include "../../gwen_amd/csrc/common.h"
 #include <type_traits>
 
 #ifndef WEAVE_VALU
@@ -108,6 +105,7 @@ __device__ inline void wait_vmcnt(int n) {
 
 // D = chunks of DMA in flight behind the one being aggregated: D = 2 needs unions of at most 128 rows
 // (3 stage buffers of 128 slots), D = 1 takes unions up to 192 (2 buffers of 192 slots).
+__device__ uint64_t *g_stamps = nullptr;
 template <int FIN, int FOUT, int NW, int D>
 __global__ __launch_bounds__(NW * 64) void k_wide(
     const int32_t *__restrict__ t_rows, const uint16_t *__restrict__ t_lid,
@@ -310,6 +308,27 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     return -1;
   };
 
+  auto mfma = [&](int ab, auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const char *abase = lds + kOffA + ab * kABytes;
+#pragma unroll
+    for (int ti = 0; ti < NTT; ++ti) {
+      const char *ap = abase + (((tt0 + ti * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(ap + k2 * 64);
+        const bf16x8 alo = *reinterpret_cast<const bf16x8 *>(ap + k2 * 64 + kAImg);
+        const int ks = 2 * c + k2;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], alo, d[ct][ti], 0, 0, 0);
+          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ct][ks], ahi, d[ct][ti], 0, 0, 0);
+          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], ahi, d[ct][ti], 0, 0, 0);
+        }
+      }
+    }
+  };
+
   // ---- prologue: chunks 0 .. D in flight, aggregate(0) -------------------------------------------------
   // chunk s = (tile s / NC, chunk s % NC) lives in stage[s % NSTG], its aggregate in A[s % 2], its tile's
   // entries in ent[(s / NC) % 3]
@@ -332,6 +351,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   //       (a few VALU instructions behind every MFMA) so that the matrix pipe paces the region.
   constexpr int NU = 2 * NTT;                          // regions per step
   constexpr int NSTAGE = 4 * NP;                       // aggregate stages: per pass 0 entries, 1 / 2 halves, 3 split
+  uint64_t tprev = __builtin_amdgcn_s_memtime();
+  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(k) do { const uint64_t tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } while (0)
   int sb = 0;                 // s % NSTG
   int eb = 0;                 // i % 3
   int young = 0;              // operations that may stay in flight at the next wait
@@ -351,8 +373,11 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
+      STAMP(0);
       wait_vmcnt(young);
+      STAMP(1);
       __syncthreads();
+      STAMP(2);
       int n_ops = 0;
       // ---- stores of tile i-1: a tile whose 64 rows all exist is stored region by region with every lane
       // active (exact instruction counts for the waits); the last tile of a member at once, guarded, drained
@@ -460,6 +485,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             }
           }
         }
+        STAMP(3);
         // aggregate stages of this region: LDS reads, then the unit's MFMAs, then the VALU work
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k)
@@ -484,6 +510,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, WEAVE_VALU, 0);     // a few VALU instructions behind it
         }
+        STAMP(4);
       });
       // what may stay in flight at the next wait: with two chunks of DMA in flight, everything this interval
       // issued (the DMA the next wait is for is older); with one, nothing (that DMA is among them)
@@ -493,6 +520,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     eb = eb + 1 == 3 ? 0 : eb + 1;
   }
   store_tile(tile_of(ntl - 1));
+  if (lane == 0 && g_stamps) for (int k = 0; k < 6; ++k) g_stamps[(blockIdx.x * NW + wave) * 6 + k] = tacc[k];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
 }
 
@@ -526,6 +554,9 @@ extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
   return fin_ok(Fin) && fout_ok(Fout) ? 1 : 0;
 }
 
+extern "C" int gwen_wide_set_stamps(uint64_t *p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
 extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
   if (!gwen_gcn_wide_supported(Fin, Fout) || N <= 0 || members <= 0) return 0;
   return Fin >= 128 || N * members >= 300000 ? 1 : 0;
