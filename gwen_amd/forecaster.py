@@ -16,7 +16,8 @@ the CPU in oracle/interaction_oracle.py):
 
 The grid is the set of triangle centres of the geodesic mesh; every cell is linked with its three
 corner vertices (gwen_amd/g2m.py).  Static embeddings (vm, e_*) depend on the weights only and are
-computed once per ``forward`` / ``rollout`` call.  Inference only.
+computed once per ``forward`` / ``rollout`` call.  Inference only.  A leading members axis
+``[members, N_grid, C]`` runs as ONE launch set over the block-diagonal graph (``ForecastGraphs.batched``).
 """
 from __future__ import annotations
 
@@ -48,6 +49,21 @@ class ForecastGraphs:
     f_g2m: Tensor           # [E, 4] each, in the STORED edge order of its graph
     f_mesh: Tensor
     f_m2g: Tensor
+    _batched: dict = None   # members -> ForecastGraphs of the block-diagonal graphs
+
+    def batched(self, members: int) -> "ForecastGraphs":
+        """Graphs and static inputs of ``members`` independent copies (EdgeGraph.batched): the c5 path rolls
+        every local member through ONE launch set per step."""
+        if members == 1:
+            return self
+        if self._batched is None:
+            self._batched = {}
+        if members not in self._batched:
+            rep = lambda t: t.repeat(members, 1)                                   # noqa: E731
+            self._batched[members] = ForecastGraphs(
+                self.g2m.batched(members), self.mesh.batched(members), self.m2g.batched(members),
+                rep(self.mesh_pos), rep(self.f_g2m), rep(self.f_mesh), rep(self.f_m2g))
+        return self._batched[members]
 
 
 class InteractionForecaster(nn.Module):
@@ -94,8 +110,14 @@ class InteractionForecaster(nn.Module):
         return grid_x + ops.linear(vg, self.readout.weight, self.readout.bias, exact=False)
 
     def forward(self, grid_x: Tensor, graphs: ForecastGraphs) -> Tensor:
+        """``grid_x`` [N_grid, C] or [members, N_grid, C] (members share graphs and weights: one launch set
+        over the block-diagonal graph)."""
         if torch.is_grad_enabled() and (grid_x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("InteractionForecaster is inference-only: call it under torch.no_grad()")
+        if grid_x.dim() == 3:
+            m = grid_x.size(0)
+            gb = graphs.batched(m)
+            return self._step(grid_x.reshape(-1, grid_x.size(-1)), gb, self._static(gb)).view_as(grid_x)
         return self._step(grid_x, graphs, self._static(graphs))
 
     def rollout(self, grid_x: Tensor, graphs: ForecastGraphs, n_steps: int,
@@ -119,23 +141,56 @@ class InteractionForecaster(nn.Module):
         return states
 
 
-def ensemble_forecast(model: InteractionForecaster, graphs: ForecastGraphs, x_members: Tensor,
-                      n_steps: int, num_members: int, group=None, graphed: bool = True) -> Tensor:
+def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
+                      n_steps: int, num_members: int, group=None, graphed: bool = True,
+                      batched: bool = True, step_cache: dict = None) -> Tensor:
     """BASELINE config c5: this rank's members ``[members_local, N_grid, C]`` are rolled out ``n_steps``
-    steps each (independent members, replicated graph and weights, one captured step replayed for all
-    of them), then every rank's final states are gathered ONCE (``ensemble.gather_members``: RCCL
-    all-gather over xGMI under the "nccl" backend).  Returns ``[num_members, N_grid, C]`` on every rank."""
+    steps (independent members, replicated graph and weights), then every rank's final states are gathered
+    ONCE (``ensemble.gather_members``: RCCL all-gather over xGMI under the "nccl" backend).  Returns
+    ``[num_members, N_grid, C]`` on every rank.
+
+    ``batched`` (default): all local members advance together -- ONE launch set per step over the
+    block-diagonal graph (``ForecastGraphs.batched``), captured once and replayed when ``graphed``.
+    ``batched=False``: one member after the other (the same arithmetic; kept for comparison).
+    ``step_cache``: a dict the captured step lives in between calls (capture costs one eager step plus the
+    capture itself; the static embeddings inside it are those of the weights at capture time).
+    ``model`` needs ``_static(graphs)`` and ``_step(x, graphs, static)`` (InteractionForecaster)."""
     from . import ensemble
-    finals = []
+    m_local = x_members.size(0)
+
+    def captured(g, x0):
+        if step_cache is None:
+            return GraphedStep(model, g, x0)
+        key = (id(model), id(g), tuple(x0.shape))
+        if key not in step_cache:
+            step_cache[key] = GraphedStep(model, g, x0)
+        return step_cache[key]
+
     with torch.no_grad():
-        step = GraphedStep(model, graphs, x_members[0]) if graphed and x_members.size(0) > 0 else None
-        static = None if step is not None else model._static(graphs)
-        for m in range(x_members.size(0)):
-            cur = x_members[m]
-            for _ in range(n_steps):
-                cur = step(cur).clone() if step is not None else model._step(cur, graphs, static)
-            finals.append(cur)
-    local = torch.stack(finals) if finals else x_members.new_empty((0,) + tuple(x_members.shape[1:]))
+        if m_local == 0:
+            local = x_members.new_empty((0,) + tuple(x_members.shape[1:]))
+        elif batched:
+            gb = graphs.batched(m_local)
+            cur = x_members.reshape(-1, x_members.size(-1))
+            if graphed:
+                step = captured(gb, cur)
+                for _ in range(n_steps):
+                    cur = step(cur).clone()
+            else:
+                static = model._static(gb)
+                for _ in range(n_steps):
+                    cur = model._step(cur, gb, static)
+            local = cur.view_as(x_members)
+        else:
+            finals = []
+            step = captured(graphs, x_members[0]) if graphed else None
+            static = None if step is not None else model._static(graphs)
+            for m in range(m_local):
+                cur = x_members[m]
+                for _ in range(n_steps):
+                    cur = step(cur).clone() if step is not None else model._step(cur, graphs, static)
+                finals.append(cur)
+            local = torch.stack(finals)
     return ensemble.gather_members(local, num_members, group)
 
 

@@ -45,10 +45,33 @@ class EdgeGraph:
     eid: Tensor           # int32 [E]  position of stored edge k in the edge_index it came from
     max_degree: int       # longest target row
     _tiles: Dict[int, Tuple[Tensor, int]] = field(default_factory=dict, repr=False)
+    _batched: Dict[int, "EdgeGraph"] = field(default_factory=dict, repr=False)
 
     @property
     def device(self) -> torch.device:
         return self.rowptr.device
+
+    def batched(self, members: int) -> "EdgeGraph":
+        """The block-diagonal graph of ``members`` independent copies (member m's nodes and edges offset by
+        m * num_src / num_dst / num_edges): ONE launch set then serves every local ensemble member -- rows
+        of all members go through the same persistent blocks, which load their weight fragments once.
+        Index plumbing only (built once per member count, kept with the graph)."""
+        if members == 1:
+            return self
+        if members not in self._batched:
+            if members < 1 or members * max(self.num_edges, self.num_src, self.num_dst) >= 2 ** 31 - 1:
+                raise ValueError("members out of range for int32 indices")
+            dev, e = self.device, self.num_edges
+            m = torch.arange(members, dtype=torch.int32, device=dev).view(-1, 1)
+            rowptr = torch.cat([(self.rowptr[:-1].view(1, -1) + m * e).reshape(-1),
+                                torch.tensor([members * e], dtype=torch.int32, device=dev)])
+            g = EdgeGraph(self.num_src * members, self.num_dst * members, e * members, rowptr.contiguous(),
+                          (self.src.view(1, -1) + m * self.num_src).reshape(-1).contiguous(),
+                          torch.empty(max(e * members, 1), dtype=torch.int32, device=dev)[:e * members],
+                          (self.eid.view(1, -1) + m * e).reshape(-1).contiguous(), self.max_degree)
+            g.tiles(64)                                   # cuts the tiles and fills dst
+            self._batched[members] = g
+        return self._batched[members]
 
     def tiles(self, rows: int) -> Tuple[Tensor, int]:
         """(tile_row int32 [n_tiles + 1], n_tiles) for a kernel that takes ``rows`` rows per pass: the

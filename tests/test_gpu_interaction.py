@@ -225,8 +225,9 @@ def test_forecaster_and_rollout_vs_oracle(ga, C, H, steps, nsteps):
 
 
 def test_ensemble_forecast_single_rank(ga):
-    """c5 shape on one rank: every member rolled out independently, gathered once (no process group:
-    the gather is the identity); graphed and eager paths agree bitwise."""
+    """c5 shape on one rank: all local members through ONE launch set per step (block-diagonal graph),
+    gathered once (no process group: the gather is the identity); batched / member-by-member and graphed /
+    eager paths agree bitwise."""
     from gwen_amd.forecaster import InteractionForecaster, ensemble_forecast
     m = ga.geodesic_mesh(4)
     torch.manual_seed(SEED)
@@ -235,9 +236,48 @@ def test_ensemble_forecast_single_rank(ga):
     xm = torch.randn(3, m.faces.shape[0], 8, device=DEV)
     a = ensemble_forecast(model, graphs, xm, 2, 3, graphed=True)
     b = ensemble_forecast(model, graphs, xm, 2, 3, graphed=False)
-    assert a.shape == (3, m.faces.shape[0], 8) and torch.equal(a, b)
+    c = ensemble_forecast(model, graphs, xm, 2, 3, graphed=False, batched=False)
+    d = ensemble_forecast(model, graphs, xm, 2, 3, graphed=True, batched=False)
+    assert a.shape == (3, m.faces.shape[0], 8) and torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     want = torch.stack([model.rollout(xm[i], graphs, 2)[-1] for i in range(3)])
     assert torch.equal(a, want)
+    with torch.no_grad():                                         # the members axis of forward()
+        one = model(xm, graphs)
+        assert torch.equal(one, torch.stack([model(xm[i], graphs) for i in range(3)]))
+
+
+@pytest.mark.parametrize("F,members", [(64, 4), (128, 3), (256, 2)])
+def test_members_axis_block_diagonal_vs_oracle(ga, F, members):
+    """[members, ...] through the batched graphs at every K6 width against the fp64 oracle per member."""
+    from gwen_amd import g2m
+    from gwen_amd.forecaster import InteractionForecaster, edge_features
+    from oracle import interaction_oracle as IO
+    m = ga.geodesic_mesh(6, reorder="hilbert")
+    C, steps = 5, 2
+    torch.manual_seed(SEED + F)
+    model = InteractionForecaster(C, F, steps)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    a, b = g2m.grid_mesh_edges(m)
+    cell = m.pos[m.faces].mean(axis=1)
+    cell /= np.linalg.norm(cell, axis=1, keepdims=True)
+    f = [torch.from_numpy(v).double() for v in (edge_features(cell, m.pos, a), edge_features(m.pos, m.pos, m.edge_index),
+                                                 edge_features(m.pos, cell, b))]
+    sd = {k: v.double() for k, v in model.state_dict().items()}
+    x0 = torch.randn(members, m.faces.shape[0], C, generator=torch.Generator().manual_seed(SEED))
+    graphs = InteractionForecaster.prepare(m, DEV)
+    gb = graphs.batched(members)
+    assert gb.mesh.num_edges == members * graphs.mesh.num_edges and gb.mesh.num_dst == members * m.num_nodes
+    assert graphs.batched(members) is gb                                  # built once
+    model = model.to(DEV)
+    with torch.no_grad():
+        got = model(x0.to(DEV), graphs)
+    for k in range(members):
+        want = IO.forecaster_step(sd, x0[k].double(), torch.from_numpy(m.pos.astype(np.float32)).double(),
+                                  torch.from_numpy(a), torch.from_numpy(m.edge_index), torch.from_numpy(b), *f, steps)
+        assert rel_err(got[k], want) <= REL_TOL
 
 
 @pytest.mark.parametrize("seed", range(16))
