@@ -80,7 +80,13 @@ SIGNATURES = {
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
     "gwen_gnn_forward_f32": (_int, [C.POINTER(GraphDesc), C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
-                                    C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32)]),
+                                    C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_void_p)]),
+    "gwen_gcn_layer_bwd_f32": (_int, [_vp] * 8 + [_i64] * 4 + [_vp]),
+    "gwen_gnn_backward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
+    "gwen_gnn_backward_f32": (_int, [C.POINTER(GraphDesc), C.POINTER(LayerDesc), C.c_int32, _vp,
+                                     C.POINTER(C.c_void_p), _vp, _vp, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), _vp, _i64, _i64, _vp]),
     "gwen_event_create": (_int, [C.POINTER(C.c_void_p)]),
     "gwen_event_destroy": (_int, [_vp]),
     "gwen_event_record": (_int, [_vp, _vp]),
@@ -90,6 +96,11 @@ SIGNATURES = {
     "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "gwen_relu_backward_f32": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gwen_gcn_grad_chunks": (_i64, [_i64]),
+    "gwen_gcn_grad_weight_partial_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "gwen_gcn_grad_bias_partial_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "gwen_reduce_chunks_batched": (_int, [_vp, C.c_int32, _vp]),
+    "gwen_transpose_batched": (_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "gwen_gcn_small_pad": (_int, [_i64]),
     "gwen_gcn_small_supported": (_int, [_i64, _i64, _i64]),
     "gwen_gcn_small_workspace_floats": (_i64, [_i64, _i64, _i64, _i64]),

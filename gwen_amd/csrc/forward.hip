@@ -69,7 +69,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
                                     int32_t n_layers, const float *x, float *out, float *scratch,
                                     int64_t scratch_floats, int64_t members, gwen_stream_t stream,
                                     void **events, gwen_launch_info *info, int32_t max_launches,
-                                    int32_t *n_launches) {
+                                    int32_t *n_launches, float *const *acts) {
   if (!graph) return GWEN_EINVAL;
   const int64_t N = graph->N;
   const int32_t *rowptr = graph->rowptr, *col = graph->col, *g_rowptr = graph->g_rowptr,
@@ -83,6 +83,9 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
   if (scratch_floats < P.total || (P.total > 4 && !scratch)) return GWEN_ENOSPACE;
   if (scratch && !gwen_aligned(scratch, 16)) return GWEN_EINVAL;
   if ((events || info) && max_launches < 2 * n_layers) return GWEN_EINVAL;
+  if (acts)
+    for (int32_t i = 0; i < n_layers; ++i)
+      if (!acts[i]) return GWEN_EINVAL;
   hipStream_t st = gwen_stream(stream);
   const int64_t rows = members * N;
   float *buf[2] = {scratch + P.ping, scratch + P.pong};
@@ -103,8 +106,8 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
 #define GWEN_TRY(expr) do { int _r = (expr); if (_r != GWEN_OK) return _r; } while (0)
 
   // AUTO layer whose widths K4 takes and that shrinks: worth gathering at fout, i.e. transform-first
-  auto shrinking_auto = [&](int32_t i) {
-    return i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin;
+  auto shrinking_auto = [&](int32_t i) {      // never while training: every layer's output must exist
+    return !acts && i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin;
   };
   const bool have_grouped = g_col && g_val;          // g_rowptr NULL = uniform layout
 
@@ -117,7 +120,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
   if (small) {
     for (int32_t i = 0; i < n_layers; ++i) {
       const gwen_layer_desc &L = layers[i];
-      float *dst = i + 1 == n_layers ? out : buf[i & 1];
+      float *dst = acts ? acts[i] : (i + 1 == n_layers ? out : buf[i & 1]);
       GWEN_TRY(before(GWEN_KIND_SMALL, i, L.fin, L.fout));
       GWEN_TRY(gwen_gcn_small_layer_f32(dense, cur, L.W, L.packed, L.bias, dst, N, L.fin, L.fout, members,
                                         N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats, stream));
@@ -137,7 +140,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
       // layer i: propagate at width fo with its bias/ReLU; chain layer i+1's projection if it shrinks
       const bool chain = !last && have_grouped && shrinking_auto(i + 1) &&
                          gwen_gcn_chain_supported(fo, layers[i + 1].fout, 0, 1);
-      float *dst = (last) ? out : buf[nbuf++ & 1];
+      float *dst = acts ? acts[i] : ((last) ? out : buf[nbuf++ & 1]);
       if (chain) {
         GWEN_TRY(before(GWEN_KIND_CHAIN, i, fo, layers[i + 1].fout));
         GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, layers[i + 1].W, nullptr, L.bias,
@@ -167,7 +170,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
                          gwen_gcn_chain_supported(fi, fo, layers[i + 1].fout, 0);
       if (!chain && L.order == GWEN_ORDER_AUTO && have_tiles &&
           gwen_gcn_wide_preferred(N, members, fi, fo)) {        // K8: the same arithmetic as K4, tile-staged
-        float *dst = last ? out : buf[nbuf++ & 1];
+        float *dst = acts ? acts[i] : (last ? out : buf[nbuf++ & 1]);
         GWEN_TRY(before(GWEN_KIND_WIDE, i, fi, fo));
         GWEN_TRY(gwen_gcn_wide_layer_f32(graph->t_rows, graph->t_lid, graph->t_val, cur, L.W, L.bias, dst,
                                          N, N, fi, fo, fo, members, N * fi, N * fo, L.relu,
@@ -178,7 +181,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
       }
       if (!have_grouped) return GWEN_EINVAL;
       // a chained kernel stores the NEXT layer's input, never the stack's output
-      float *dst = (last && !chain) ? out : buf[nbuf++ & 1];
+      float *dst = acts ? acts[i] : ((last && !chain) ? out : buf[nbuf++ & 1]);
       if (chain) {
         GWEN_TRY(before(GWEN_KIND_CHAIN, i, fi, layers[i + 1].fout));
         GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, L.W, layers[i + 1].W, L.bias, dst,
@@ -195,7 +198,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
       }
       cur = dst;
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
-      float *dst = last ? out : buf[nbuf++ & 1];
+      float *dst = acts ? acts[i] : (last ? out : buf[nbuf++ & 1]);
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
       GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, L.order != GWEN_ORDER_AUTO, lin_ws,
                                    P.lin_floats, stream));
@@ -206,7 +209,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
       GWEN_TRY(after());
       cur = dst;
     } else if (o == GWEN_ORDER_AGGREGATE_FIRST) {
-      float *dst = last ? out : buf[nbuf++ & 1];
+      float *dst = acts ? acts[i] : (last ? out : buf[nbuf++ & 1]);
       GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fi, fi));
       GWEN_TRY(gwen_gcn_propagate_f32(rowptr, col, val, cur, nullptr, tmp, N, fi, fi, fi, members,
                                       N * fi, N * fi, 0, stream));

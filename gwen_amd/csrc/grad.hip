@@ -124,6 +124,47 @@ __global__ void k_relu_bwd(const float *__restrict__ y, const float *__restrict_
 
 inline int64_t nchunks_for(int64_t rows) { return rows > 0 ? (rows + kChunkRows - 1) / kChunkRows : 1; }
 
+// k_reduce_chunks for up to GWEN_MAX_REDUCE_TASKS (partial, dst, count, nchunks) tasks in ONE launch: the
+// finish stages of every grad_W / grad_b of a backward pass (blockIdx.y = task).
+struct TaskTable { gwen_reduce_task t[GWEN_MAX_REDUCE_TASKS]; };
+__global__ __launch_bounds__(kThreads) void k_reduce_tasks(TaskTable tab) {
+  __shared__ float red[kThreads];
+  const gwen_reduce_task tk = tab.t[blockIdx.y];
+  const int64_t count = tk.count;
+  if ((int64_t)blockIdx.x * 16 >= count) return;
+  const int nchunks = (int)tk.nchunks;
+  const int e = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int64_t j = (int64_t)blockIdx.x * 16 + e, jc = j < count ? j : count - 1;
+  float s = 0.0f;
+  for (int c = ph; c < nchunks; c += 16 * kU) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int cc = c + 16 * u < nchunks ? c + 16 * u : nchunks - 1;
+      v[u] = tk.partial[(int64_t)cc * count + jc];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (c + 16 * u < nchunks) s = s + v[u];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ph == 0 && j < count) {
+    float tot = red[e];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) tot = tot + red[16 * p + e];
+    tk.dst[j] = tot;
+  }
+}
+
+struct TransposeTable { const float *w[GWEN_MAX_REDUCE_TASKS]; float *wt[GWEN_MAX_REDUCE_TASKS];
+                        int rows[GWEN_MAX_REDUCE_TASKS], cols[GWEN_MAX_REDUCE_TASKS]; };
+__global__ void k_transpose_tasks(TransposeTable tab) {            // wt [cols, rows] = w [rows, cols]^T
+  const int k = blockIdx.y, rows = tab.rows[k], cols = tab.cols[k];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * cols) tab.wt[k][(i % cols) * rows + i / cols] = tab.w[k][i];
+}
+
 }  // namespace
 
 extern "C" int64_t gwen_gcn_grad_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout) {
@@ -188,6 +229,75 @@ extern "C" int gwen_relu_backward_f32(const float *y, const float *g, float *gin
   const int64_t blocks = (count + 255) / 256;
   if (blocks > 0x7fffffffLL) return GWEN_ERANGE;
   k_relu_bwd<<<(unsigned)blocks, 256, 0, gwen_stream(stream_)>>>(y, g, gin, count);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+// ---- building blocks of the whole-stack backward (gwen_gnn_backward_f32) --------------------------------------
+// Stage 1 only: per-chunk partial sums [nchunks, Fout * Fin] / [nchunks, F] (nchunks = gwen_gcn_grad_chunks(rows));
+// the fixed-order finish of MANY such reductions is one gwen_reduce_chunks_batched launch.
+extern "C" int64_t gwen_gcn_grad_chunks(int64_t rows) { return nchunks_for(rows); }
+
+extern "C" int gwen_gcn_grad_weight_partial_f32(const float *g, const float *x, float *partial, int64_t rows,
+                                                int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx,
+                                                gwen_stream_t stream_) {
+  if (rows <= 0 || Fin <= 0 || Fout <= 0 || ldg < Fout || ldx < Fin || !g || !x || !partial) return GWEN_EINVAL;
+  if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
+  const int64_t nc = nchunks_for(rows);
+  const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
+  const int64_t ntiles = (int64_t)tiles_i * tiles_o;
+  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL) return GWEN_ERANGE;
+  dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
+  k_grad_w<<<grid, kThreads, 0, gwen_stream(stream_)>>>(g, x, partial, rows, (int)Fin, (int)Fout, ldg, ldx,
+                                                        tiles_i, (int)ntiles);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+extern "C" int gwen_gcn_grad_bias_partial_f32(const float *g, float *partial, int64_t rows, int64_t F,
+                                              int64_t ldg, gwen_stream_t stream_) {
+  if (rows <= 0 || F <= 0 || ldg < F || !g || !partial) return GWEN_EINVAL;
+  const int64_t nc = nchunks_for(rows);
+  if ((F + 63) / 64 > 65535 || nc > 0x7fffffffLL) return GWEN_ERANGE;
+  dim3 grid((unsigned)nc, (unsigned)((F + 63) / 64));
+  k_grad_b<<<grid, kThreads, 0, gwen_stream(stream_)>>>(g, partial, rows, (int)F, ldg);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+extern "C" int gwen_reduce_chunks_batched(const gwen_reduce_task *tasks, int32_t n_tasks, gwen_stream_t stream_) {
+  if (n_tasks < 0 || n_tasks > GWEN_MAX_REDUCE_TASKS || (n_tasks > 0 && !tasks)) return GWEN_EINVAL;
+  if (n_tasks == 0) return GWEN_OK;
+  TaskTable tab;
+  int64_t cmax = 0;
+  for (int i = 0; i < n_tasks; ++i) {
+    if (!tasks[i].partial || !tasks[i].dst || tasks[i].count <= 0 || tasks[i].nchunks <= 0 ||
+        tasks[i].nchunks > 0x7fffffffLL)
+      return GWEN_EINVAL;
+    tab.t[i] = tasks[i];
+    if (tasks[i].count > cmax) cmax = tasks[i].count;
+  }
+  if ((cmax + 15) / 16 > 0x7fffffffLL) return GWEN_ERANGE;
+  dim3 grid((unsigned)((cmax + 15) / 16), (unsigned)n_tasks);
+  k_reduce_tasks<<<grid, kThreads, 0, gwen_stream(stream_)>>>(tab);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+extern "C" int gwen_transpose_batched(const float *const *w, float *const *wt, const int32_t *rows,
+                                      const int32_t *cols, int32_t n, gwen_stream_t stream_) {
+  if (n < 0 || n > GWEN_MAX_REDUCE_TASKS || (n > 0 && (!w || !wt || !rows || !cols))) return GWEN_EINVAL;
+  if (n == 0) return GWEN_OK;
+  TransposeTable tab;
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || !wt[i] || rows[i] <= 0 || cols[i] <= 0 || (int64_t)rows[i] * cols[i] > 0x7fffffffLL)
+      return GWEN_EINVAL;
+    tab.w[i] = w[i]; tab.wt[i] = wt[i]; tab.rows[i] = rows[i]; tab.cols[i] = cols[i];
+    if (rows[i] * cols[i] > cmax) cmax = rows[i] * cols[i];
+  }
+  dim3 grid((unsigned)((cmax + 255) / 256), (unsigned)n);
+  k_transpose_tasks<<<grid, 256, 0, gwen_stream(stream_)>>>(tab);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }

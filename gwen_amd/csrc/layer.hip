@@ -71,12 +71,16 @@ struct Cfg {
   static_assert(BR % RB == 0 && BR % kTile == 0, "a block is whole gather passes and whole row tiles");
 };
 
-template <int FIN, int FOUT, bool SPLIT, int BRMIN, bool UNI = false>
+// BWD (the layer's backward, gwen_gcn_layer_bwd_f32): the aggregated rows are also stored (agg_out: the
+// operand of grad_W) and the result is masked by mask > 0 (the ReLU of the layer below), so the launch
+// returns the gradient the next backward launch starts from.
+template <int FIN, int FOUT, bool SPLIT, int BRMIN, bool UNI = false, bool BWD = false>
 __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void k_layer(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int64_t ldo,
-    int64_t mstride_x, int64_t mstride_o, int relu) {
+    int64_t mstride_x, int64_t mstride_o, int relu, float *__restrict__ agg_out = nullptr,
+    const float *__restrict__ mask = nullptr) {
   using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
   float *tile = reinterpret_cast<float *>(lds_raw);                      // exact: [BR][PF] fp32
@@ -132,6 +136,11 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   // ---- phase 1: gather + aggregate into the LDS tile (gather_rows.h) ------------------------------
   gwen::gather_passes<FIN, C::NP, C::RB, UNI>(
       rowptr, col, val, xb, N, b0, wave, gr, lane_off, [&](int lr, float4_t acc) {
+        if constexpr (BWD) {
+          if (agg_out && b0 + lr < N)
+            *reinterpret_cast<float4_t *>(agg_out + (int64_t)blockIdx.y * mstride_x +
+                                          (int64_t)(b0 + lr) * FIN + gl * 4) = acc;
+        }
         if constexpr (SPLIT) {
           const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
           bf16x4 h4, l4;
@@ -182,6 +191,14 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
 #pragma unroll
       for (int t = 0; t < 4; ++t) o[t] = o[t] < 0.0f ? 0.0f : o[t];
     }
+    if constexpr (BWD) {
+      if (mask && r < N) {
+        const float4_t y = *reinterpret_cast<const float4_t *>(mask + (int64_t)blockIdx.y * mstride_o +
+                                                               (int64_t)r * ldo + j * 16 + 4 * mh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = y[t] > 0.0f ? o[t] : 0.0f;
+      }
+    }
     if (r < N) *reinterpret_cast<float4_t *>(om + (int64_t)r * ldo + j * 16 + 4 * mh) = o;
   }
   if constexpr (kPersist) __syncthreads();     // the tile is free for the next chunk
@@ -191,7 +208,8 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
 template <int FIN, int FOUT, bool SPLIT, int BRMIN>
 int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
                 const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
-                int64_t msx, int64_t mso, int relu, hipStream_t st, bool probe, int64_t *resident_out) {
+                int64_t msx, int64_t mso, int relu, hipStream_t st, bool probe, int64_t *resident_out,
+                float *agg_out = nullptr, const float *mask = nullptr, bool bwd = false) {
   using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
   static int per_cu = 0;
   if (per_cu == 0) {
@@ -206,6 +224,18 @@ int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, con
   int64_t blocks = (N + C::BR - 1) / C::BR;
   if (FIN * FOUT >= 128 * 128 && blocks > resident) blocks = resident;   // wide layer: one resident set
   dim3 grid((unsigned)blocks, (unsigned)members);
+  if constexpr (SPLIT) {
+    if (bwd) {
+      if (!rowptr)
+        k_layer<FIN, FOUT, SPLIT, BRMIN, true, true><<<grid, C::NWB * 64, 0, st>>>(
+            rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask);
+      else
+        k_layer<FIN, FOUT, SPLIT, BRMIN, false, true><<<grid, C::NWB * 64, 0, st>>>(
+            rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask);
+      GWEN_LAUNCH_CHECK();
+      return GWEN_OK;
+    }
+  }
   if (!rowptr)      // uniform layout: row r is the group at 8 r
     k_layer<FIN, FOUT, SPLIT, BRMIN, true><<<grid, C::NWB * 64, 0, st>>>(
         rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu);
@@ -219,10 +249,11 @@ int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, con
 template <int FIN, int FOUT, bool SPLIT>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
-           int64_t msx, int64_t mso, int relu, hipStream_t st) {
+           int64_t msx, int64_t mso, int relu, hipStream_t st, float *agg_out = nullptr,
+           const float *mask = nullptr, bool bwd = false) {
 #define GWEN_ROWS(BRV, PROBE, RES)                                                                  \
   launch_rows<FIN, FOUT, SPLIT, BRV>(rowptr, col, val, x, W, bias, out, N, ldo, members, msx, mso,  \
-                                     relu, st, PROBE, RES)
+                                     relu, st, PROBE, RES, agg_out, mask, bwd)
   if constexpr (FIN <= 64 && FOUT <= 64) {
     // Narrow layers run as ONE round of co-resident blocks when a block size makes that possible: with
     // 64-row blocks the c2 mesh needs 1 563 blocks against 1 024 resident ones (4 per CU at 64 -> 64),
@@ -284,6 +315,38 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
                                          mstride_x, mstride_o, relu, st)                         \
                  : launch<FI, FO, true>(rowptr, col, val, x, W, bias, out, N, ldo, members,      \
                                         mstride_x, mstride_o, relu, st)
+  GWEN_L(16, 16); GWEN_L(16, 32); GWEN_L(16, 64); GWEN_L(16, 128);
+  GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);
+  GWEN_L(64, 16); GWEN_L(64, 32); GWEN_L(64, 64); GWEN_L(64, 128);
+  GWEN_L(128, 16); GWEN_L(128, 32); GWEN_L(128, 64); GWEN_L(128, 128);
+  GWEN_L(16, 256); GWEN_L(32, 256); GWEN_L(64, 256); GWEN_L(128, 256);
+  GWEN_L(256, 16); GWEN_L(256, 32); GWEN_L(256, 64); GWEN_L(256, 128); GWEN_L(256, 256);
+#undef GWEN_L
+  return GWEN_EINVAL;
+}
+
+// The layer's backward as ONE launch of the same kernel on the TRANSPOSED graph (grouped arrays of the
+// transposed CSR):  gh = A~^T g  (stored: grad_W = gh^T x is a separate reduction),  gx = gh Wt^T  masked
+// by mask > 0.  g [members, N, Fg]; Wt [Fx, Fg] = the layer's weight as stored ([out, in] = [Fg, Fx])
+// TRANSPOSED; gh [members, N, Fg]; gx, mask [members, N, Fx] (mask NULL = no ReLU below).
+extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
+                                      const float *g, const float *Wt, const float *mask, float *gh,
+                                      float *gx, int64_t N, int64_t Fg, int64_t Fx, int64_t members,
+                                      gwen_stream_t stream_) {
+  if (N < 0 || members < 0) return GWEN_EINVAL;
+  if (!gwen_gcn_layer_supported(Fg, Fx)) return GWEN_EINVAL;
+  if (N == 0 || members == 0) return GWEN_OK;
+  if (!t_col || !t_val || !g || !Wt || !gx || g == gx) return GWEN_EINVAL;
+  if (N >= (int64_t(1) << 28) || members > 65535) return GWEN_ERANGE;
+  if (!gwen_aligned(g, 16) || !gwen_aligned(gx, 16) || !gwen_aligned(Wt, 16) ||
+      (gh && !gwen_aligned(gh, 16)) || (mask && !gwen_aligned(mask, 16)))
+    return GWEN_EINVAL;
+  if (N * Fg * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;
+  hipStream_t st = gwen_stream(stream_);
+#define GWEN_L(FI, FO)                                                                           \
+  if (Fg == FI && Fx == FO)                                                                      \
+    return launch<FI, FO, true>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,     \
+                                N * Fg, N * Fx, 0, st, gh, mask, true)
   GWEN_L(16, 16); GWEN_L(16, 32); GWEN_L(16, 64); GWEN_L(16, 128);
   GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);
   GWEN_L(64, 16); GWEN_L(64, 32); GWEN_L(64, 64); GWEN_L(64, 128);

@@ -178,7 +178,9 @@ class StackForward:
         return self._gd
 
     def run(self, x: Tensor, out: Optional[Tensor] = None,
-            events: Optional[KernelEvents] = None) -> Tensor:
+            events: Optional[KernelEvents] = None, acts: Optional[List[Tensor]] = None) -> Tensor:
+        """``acts``: list of n_layers output tensors ([..., N, fout_l]) -- the TRAINING forward: every
+        layer's output is kept (``acts[-1]`` is the result) and no projection is chained across layers."""
         if not x.is_cuda:
             raise RuntimeError("gwen_amd: x must live on a HIP device (no CPU fallback)")
         if x.dtype != torch.float32:
@@ -194,6 +196,12 @@ class StackForward:
         if x.size(-2) != n or x.size(-1) != self.fin:
             raise ValueError(f"x is {tuple(x.shape)}, expected [..., {n}, {self.fin}]")
         dev = x.device
+        acts_arr = None
+        if acts is not None:
+            if len(acts) != len(self.desc):
+                raise ValueError("acts must hold one tensor per layer")
+            acts_arr = (C.c_void_p * len(acts))(*[a.data_ptr() for a in acts])
+            out = acts[-1]
         if out is None:
             out = torch.empty(*x.shape[:-1], self.fout, dtype=torch.float32, device=dev)
         scratch = self._scratch_for(members, dev)
@@ -205,9 +213,74 @@ class StackForward:
                 None if events is None else events._ev,
                 None if events is None else events.info,
                 0 if events is None else events.max_launches,
-                None if events is None else C.byref(events.n))
+                None if events is None else C.byref(events.n), acts_arr)
         _lib.check(rc, "gwen_gnn_forward_f32")
         return out
+
+
+class GNNStackFunction(torch.autograd.Function):
+    """The whole GCN stack as ONE autograd node: forward = ``gwen_gnn_forward_f32`` keeping every layer's
+    output, backward = ``gwen_gnn_backward_f32`` -- one host call each (the reference's train step,
+    /root/reference/src/gwen/models_gnn.py:365-373, runs ~25 eager launches per layer and direction).
+    ``flat`` = weight_0, bias_0, weight_1, bias_1, ...; ``spec`` = ((relu, order), ...) per layer."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, graph: GraphCSR, spec, *flat):
+        layers = [(flat[2 * i], flat[2 * i + 1], spec[i][0], spec[i][1]) for i in range(len(spec))]
+        plan = StackForward(layers, graph)
+        if plan._small:
+            raise RuntimeError("GNNStackFunction is for graphs beyond K7's 256 nodes")
+        xc = x.contiguous()
+        acts = [torch.empty(*xc.shape[:-1], w.size(0), dtype=torch.float32, device=xc.device)
+                for w, _, _, _ in layers]
+        plan.run(xc, acts=acts)
+        ctx.plan, ctx.graph, ctx.n = plan, graph, len(spec)
+        ctx.save_for_backward(xc, *acts)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        xc, *acts = ctx.saved_tensors
+        plan, g, n = ctx.plan, ctx.graph, ctx.n
+        dev = xc.device
+        members = 1 if xc.dim() == 2 else xc.size(0)
+        go = grad_out.contiguous()
+        t_rowptr, t_col, t_val = g.transposed()
+        gr, gc, gv = g.transposed_grouped()
+        gd = _lib.GraphDesc()
+        gd.N = g.num_nodes
+        gd.rowptr, gd.col, gd.val = t_rowptr.data_ptr(), t_col.data_ptr(), t_val.data_ptr()
+        gd.g_rowptr = 0 if gr is None else gr.data_ptr()
+        gd.g_col, gd.g_val = gc.data_ptr(), gv.data_ptr()
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(xc) if need[0] else None
+        gws = [torch.empty_like(plan._keep[3 * i]) if need[3 + 2 * i] else None for i in range(n)]
+        gbs = [torch.empty_like(plan._keep[3 * i + 1]) if (plan._keep[3 * i + 1] is not None and need[4 + 2 * i])
+               else None for i in range(n)]
+        arr = lambda ts: (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])      # noqa: E731
+        L = _lib.lib()
+        nfl = int(L.gwen_gnn_backward_scratch_floats(g.num_nodes, members, plan.desc, n))
+        if nfl < 0:
+            _lib.check(nfl, "gwen_gnn_backward_scratch_floats")
+        scratch = torch.empty(max(nfl, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.gwen_gnn_backward_f32(C.byref(gd), plan.desc, n, _ptr(xc), arr(acts), _ptr(go), _ptr(gx),
+                                         arr(gws), arr(gbs), _ptr(scratch), scratch.numel(), members,
+                                         _stream(dev))
+        _lib.check(rc, "gwen_gnn_backward_f32")
+        flat = []
+        for w, b in zip(gws, gbs):
+            flat += [w, b]
+        return (gx, None, None, *flat)
+
+
+def stack_apply(x: Tensor, graph: GraphCSR, layers: Sequence[Tuple[Tensor, Optional[Tensor], bool, str]]) -> Tensor:
+    """Differentiable forward of a GCN stack through ``GNNStackFunction``."""
+    spec = tuple((bool(r), o) for _, _, r, o in layers)
+    flat = []
+    for w, b, _, _ in layers:
+        flat += [w, b]
+    return GNNStackFunction.apply(x, graph, spec, *flat)
 
 
 class GraphedForward:

@@ -77,6 +77,25 @@ class GCNConv(nn.Module):
             nn.init.zeros_(self.bias)
         self._cached_graph = None
 
+    @property
+    def precision(self) -> str:
+        """"3xbf16" (default): contractions on the bf16 matrix cores as a 3-term hi/lo split with fp32
+        accumulation (fp32 storage; ~16-17 mantissa bits per product, 7e-6 relative on the 6-layer model);
+        "fp32": the fp32-input MFMA (exact fp32 products, bit-identical to a k-ordered fmaf chain).  The same
+        rule holds in training and inference, in the per-layer path and in the stack launcher."""
+        return "3xbf16" if self.order == "auto" else "fp32"
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value == "3xbf16":
+            self.order = "auto"
+        elif value == "fp32":
+            from .ops import layer_supported
+            self.order = "fused_exact" if layer_supported(self.in_channels, self.out_channels) else \
+                ("aggregate_first" if self.in_channels < self.out_channels else "transform_first")
+        else:
+            raise ValueError('precision must be "3xbf16" or "fp32"')
+
     # the prepared graph holds device tensors; never pickle it with the module
     def __getstate__(self):
         state = self.__dict__.copy()

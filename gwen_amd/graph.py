@@ -49,6 +49,7 @@ class GraphCSR:
     _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
     _dense: Optional[Tensor] = field(default=None, repr=False)
     _tiles: Optional[tuple] = field(default=None, repr=False)
+    _tgrouped: Optional[tuple] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -92,6 +93,16 @@ class GraphCSR:
                 flag, umax = (int(v) for v in st.tolist())
                 self._tiles = ((t_rows, t_lid, t_val, umax),) if flag == 0 else (None,)
         return self._tiles[0]
+
+    def transposed_grouped(self) -> Tuple[Optional[Tensor], Tensor, Tensor]:
+        """Grouped layout (gwen_gcn_group8) of the TRANSPOSED CSR: what K4's kernel walks in the backward
+        pass (gwen_gcn_layer_bwd_f32).  Built on first use."""
+        if self._tgrouped is None:
+            t_rowptr, t_col, t_val = self.transposed()
+            shadow = GraphCSR(self.num_nodes, self.num_edges, t_rowptr, t_col, t_val, self.eid, self.dis,
+                              self.status)
+            self._tgrouped = _grouped_impl(shadow)
+        return self._tgrouped
 
     def dense(self) -> Optional[Tensor]:
         """The graph as a dense padded fp32 matrix for K7 (square graphs of at most 256 nodes: the

@@ -271,6 +271,10 @@ class GCNLayerFunction(torch.autograd.Function):
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], graph: GraphCSR,
                 relu: bool, order: str, packed: Optional[Tensor] = None) -> Tensor:
         fout, fin = weight.shape
+        # one precision rule for both host paths (this Function and the stack launcher, forward.hip): an AUTO
+        # layer contracts with the 3xbf16 split whatever kernels it resolves to; explicit orders
+        # ("transform_first", "aggregate_first", "fused_exact") use the exact fp32-input MFMA
+        exact = order != "auto"
         if order == "auto":
             if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout):
                 order = "small"              # K7: the reference's member graphs (<= 256 nodes)
@@ -290,12 +294,12 @@ class GCNLayerFunction(torch.autograd.Function):
             out = layer_fused(graph, x, weight, bias, relu, exact=(order == "fused_exact"))
             saved_in = x
         elif order == "transform_first":
-            h = linear(x, weight)
+            h = linear(x, weight, exact=exact)
             out = propagate(graph, h, bias, relu)
             saved_in = x
         elif order == "aggregate_first":
             agg = propagate(graph, x)
-            out = linear(agg, weight, bias, relu)
+            out = linear(agg, weight, bias, relu, exact=exact)
             saved_in = agg
         else:
             raise ValueError(f"unknown order {order!r}")

@@ -221,6 +221,9 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
  *   with gwen_gcn_wide_preferred() run as K8.
  * x [members, N, layers[0].fin] and out [members, N, layers[n-1].fout] contiguous; out != x.
  * scratch: fp32 workspace of gwen_gnn_forward_scratch_floats() elements (16-byte aligned).
+ * acts (HOST array of n_layers device pointers, or NULL): the TRAINING forward -- layer l's output is
+ *   stored in acts[l] ([members, N, layers[l].fout]; acts[n_layers-1] may be `out`) and no projection is
+ *   chained across layers (every activation the backward needs exists).
  * events (HOST array of hipEvent_t, or NULL): if given, events[2i] / events[2i+1] are recorded on
  *   `stream` right before / after kernel launch i; info[i] (HOST, or NULL) says what launch i was.
  *   n_launches (HOST, or NULL) receives the number of launches; max_launches bounds both arrays.
@@ -266,7 +269,8 @@ int64_t gwen_gnn_forward_scratch_floats(int64_t N, int64_t members, const gwen_l
 int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_desc *layers, int32_t n_layers,
                          const float *x, float *out, float *scratch, int64_t scratch_floats,
                          int64_t members, gwen_stream_t stream, void **events,
-                         gwen_launch_info *info, int32_t max_launches, int32_t *n_launches);
+                         gwen_launch_info *info, int32_t max_launches, int32_t *n_launches,
+                         float *const *acts);
 
 /* ---------------------------------------------------------------------------------------------
  * K7  a whole GCNConv layer on a SMALL graph (N <= 256) with wide features -- the reference's own
@@ -322,6 +326,54 @@ int gwen_gcn_grad_bias_f32(const float *g, float *grad_b, int64_t rows, int64_t 
                            float *partial, gwen_stream_t stream);
 int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t count,
                            gwen_stream_t stream);
+/* Building blocks of gwen_gnn_backward_f32: stage 1 of the two reductions alone (per-chunk partial sums,
+ * [gwen_gcn_grad_chunks(rows), Fout * Fin] and [.., F]), the fixed-order finish of up to
+ * GWEN_MAX_REDUCE_TASKS such reductions in ONE launch (dst[j] = sum over chunks of partial[c * count + j]),
+ * and up to GWEN_MAX_REDUCE_TASKS small transposes (wt [cols, rows] = w [rows, cols]^T) in one launch.
+ * tasks / w / wt / rows / cols are HOST arrays (they travel as kernel arguments). */
+#define GWEN_MAX_REDUCE_TASKS 32
+typedef struct gwen_reduce_task {
+  const float *partial;
+  float *dst;
+  int64_t count, nchunks;
+} gwen_reduce_task;
+int64_t gwen_gcn_grad_chunks(int64_t rows);
+int gwen_gcn_grad_weight_partial_f32(const float *g, const float *x, float *partial, int64_t rows,
+                                     int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx,
+                                     gwen_stream_t stream);
+int gwen_gcn_grad_bias_partial_f32(const float *g, float *partial, int64_t rows, int64_t F, int64_t ldg,
+                                   gwen_stream_t stream);
+int gwen_reduce_chunks_batched(const gwen_reduce_task *tasks, int32_t n_tasks, gwen_stream_t stream);
+int gwen_transpose_batched(const float *const *w, float *const *wt, const int32_t *rows,
+                           const int32_t *cols, int32_t n, gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of a whole layer / of the whole stack (the reference's loss.backward(),
+ * /root/reference/src/gwen/models_gnn.py:372, through six GCNConv layers).
+ *
+ * gwen_gcn_layer_bwd_f32: K4's kernel on the TRANSPOSED graph (t_* = gwen_gcn_group8 of gwen_gcn_transpose):
+ *     gh = A~^T g                         stored (the operand of grad_W = gh^T x); gh may be NULL
+ *     gx = (gh Wt^T) masked by mask > 0   Wt [Fx, Fg] = the layer's lin.weight ([Fg, Fx]) transposed;
+ *                                         mask = the output of the layer below when it has a ReLU, or NULL
+ *   g, gh [members, N, Fg]; gx, mask [members, N, Fx], contiguous; widths as gwen_gcn_layer_supported(Fg, Fx).
+ * gwen_gnn_backward_f32: all layers, last to first, from one host call: per layer grad_b (column sums of
+ *   the incoming, already masked gradient), the launch above (or K2^T + K3 + mask where the widths are not
+ *   K4's), grad_W.  graph_t: the views of the TRANSPOSED graph (rowptr/col/val and, for the fused launch,
+ *   g_rowptr/g_col/g_val).  acts (HOST array of n_layers device pointers): every layer's output as the
+ *   training forward stored it (gwen_gnn_forward_f32 with acts); x: the stack's input; grad_out: gradient of
+ *   the last layer's output.  grad_x may be NULL; grad_W / grad_b: HOST arrays of device pointers (NULL array
+ *   or NULL entry = not wanted).  scratch: gwen_gnn_backward_scratch_floats() fp32 elements.
+ * ------------------------------------------------------------------------------------------- */
+int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
+                           const float *g, const float *Wt, const float *mask, float *gh, float *gx,
+                           int64_t N, int64_t Fg, int64_t Fx, int64_t members, gwen_stream_t stream);
+int64_t gwen_gnn_backward_scratch_floats(int64_t N, int64_t members, const struct gwen_layer_desc *layers,
+                                         int32_t n_layers);
+int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_layer_desc *layers,
+                          int32_t n_layers, const float *x, const float *const *acts,
+                          const float *grad_out, float *grad_x, float *const *grad_W,
+                          float *const *grad_b, float *scratch, int64_t scratch_floats, int64_t members,
+                          gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6 -- InteractionNet block: edge MLP + sum to target nodes, and the node MLP  (SURVEY 8(f) f2).

@@ -202,9 +202,9 @@ def test_layer_vs_oracle(ga, cref, case, fin, fout, order):
     ref64 = torch.from_numpy(cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), f64=True))
     assert rel_err(got, ref) <= REL_TOL
     assert rel_err(got, ref64) <= REL_TOL
-    # exact paths should be no further from fp64 truth than the fp32 oracle is (x4 slack); the
-    # default K4 contraction (3xbf16) is allowed 2e-5
-    slack = 2e-5 if (order == "auto" and ops.layer_supported(fin, fout)) else 1e-6
+    # exact paths (explicit orders) should be no further from fp64 truth than the fp32 oracle is (x4 slack);
+    # the default contraction of an AUTO layer (3xbf16, whatever kernels it resolves to) is allowed 2e-5
+    slack = 2e-5 if order == "auto" else 1e-6
     assert rel_err(got, ref64) <= 4 * rel_err(ref, ref64) + slack
 
 
@@ -346,10 +346,16 @@ def test_stack_forward_equals_layer_by_layer(ga, members, C, H):
     # the launcher re-brackets shrinking layers (K5 chains their projection), so equality is to
     # rounding, not to the bit; with explicit per-layer orders it is bit for bit
     assert rel_err(one_call, layered) <= 2e-5
-    explicit = [(w, b, r, "fused" if ga.ops.layer_supported(w.size(1), w.size(0)) else
-                 ("aggregate_first" if w.size(1) < w.size(0) else "transform_first"))
-                for w, b, r, _ in model.stack()]
-    assert torch.equal(ga.StackForward(explicit, g).run(x), layered)
+    # with the same explicit per-layer orders on both sides it is bit for bit
+    convs = [c for c in model.modules() if isinstance(c, ga.GCNConv)]
+    for c in convs:
+        c.order = "fused" if ga.ops.layer_supported(c.in_channels, c.out_channels) else \
+            ("aggregate_first" if c.in_channels < c.out_channels else "transform_first")
+    layered_explicit = model.conv_layers(x.clone().requires_grad_(), g).detach()
+    assert torch.equal(ga.StackForward(model.stack(), g).run(x), layered_explicit)
+    assert rel_err(layered_explicit, layered) <= 2e-5
+    for c in convs:
+        c.order = "auto"
     ev = ga.KernelEvents(12)
     again = ga.StackForward(model.stack(), g).run(x, events=ev)
     assert torch.equal(again, one_call)
@@ -379,10 +385,12 @@ def test_kat_complete_graph_is_mean(ga):
     assert rel_err(got, want.expand_as(got)) <= 1e-5
 
 
-def test_kat_path_and_cycle(ga):
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-6), ("3xbf16", 2e-5)])
+def test_kat_path_and_cycle(ga, precision, tol):
     fin = fout = 4
     eye = torch.eye(4)
     conv = ga.GCNConv(fin, fout).to(DEV)
+    conv.precision = precision
     with torch.no_grad():
         conv.lin.weight.copy_(eye); conv.bias.zero_()
     x = torch.randn(3, 4, generator=torch.Generator().manual_seed(SEED)).double()
@@ -390,12 +398,12 @@ def test_kat_path_and_cycle(ga):
     got = conv(x.float().to(DEV), ei.to(DEV)).detach().cpu().double()
     r6 = 1 / 6 ** 0.5
     want = torch.stack([x[0] / 2 + x[1] * r6, x[0] * r6 + x[1] / 3 + x[2] * r6, x[1] * r6 + x[2] / 2])
-    assert rel_err(got, want) <= 1e-6
+    assert rel_err(got, want) <= tol
     x = torch.randn(6, 4, generator=torch.Generator().manual_seed(SEED)).double()
     ei = torch.tensor([[0, 1, 2, 3, 4, 5], [1, 2, 3, 4, 5, 0]])
     got = conv(x.float().to(DEV), ei.to(DEV)).detach().cpu().double()
     want = 0.5 * (x + torch.roll(x, 1, 0))
-    assert rel_err(got, want) <= 1e-6
+    assert rel_err(got, want) <= tol
 
 
 def test_properties_full_size(ga):
@@ -472,3 +480,110 @@ def test_model_training_step(ga):
     live = (".conv1.", ".conv2.", ".conv3.", ".upconv3.", ".upconv4.", ".upconv5.")
     for n_, p in model.named_parameters():
         assert (p.grad is not None) == any(k in n_ for k in live), n_
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-stack training path: gwen_gnn_forward_f32 (acts) + gwen_gnn_backward_f32, one host call each
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("members", [1, 3])
+@pytest.mark.parametrize("C,H", [(64, 64), (8, 16), (20, 48), (32, 128), (16, 256)])
+def test_stack_backward_vs_oracle_autograd(ga, C, H, members):
+    """Every gradient of GNNModel (x, 6 weights, 6 biases) through the stack launchers against torch autograd
+    on the CPU oracle -- widths K4's backward kernel takes (fused launch) and widths it does not (K2^T + K3)."""
+    from oracle import gcn_oracle as O
+    m = ga.geodesic_mesh(7, reorder="hilbert")
+    n = m.num_nodes                                     # 492 > 256: not the K7 path
+    ei = torch.from_numpy(m.edge_index)
+    torch.manual_seed(SEED)
+    ref = O.OracleGNNModel(O.OracleGNNConfig(n, n, C, C, H))
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    model = ga.GNNModel(ga.GNNConfig(n, n, C, C, H))
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(DEV)
+    x = torch.randn(members, n, C, generator=torch.Generator().manual_seed(SEED))
+    gout = torch.randn(members, n, C, generator=torch.Generator().manual_seed(SEED + 1))
+    xr = x.clone().requires_grad_()
+    torch.stack([ref(xr[k], ei) for k in range(members)]).backward(gout)
+    xd = (x if members > 1 else x[0]).to(DEV).requires_grad_()
+    out = model(xd, ei.to(DEV))
+    assert out.grad_fn is not None and "GNNStackFunction" in type(out.grad_fn).__name__
+    out.backward((gout if members > 1 else gout[0]).to(DEV))
+    with torch.no_grad():
+        want = torch.stack([ref(x[k], ei) for k in range(members)])
+    assert rel_err(out.detach().view(members, n, C), want) <= REL_TOL
+
+    # A pre-activation within rounding of zero can fall on the other side of a ReLU than in the oracle: that
+    # member's gradient then differs at 1e-4..1e-3 in a neighbourhood of the unit (seen: 35 rows of one
+    # member; up to 1e-2 through a 12-wide bottleneck), while every other member agrees to 1e-5.  So: the median member must meet the tolerance, every
+    # member a looser bound, and the device's own two paths (below) must agree to rounding.
+    def l2_err(a, b):
+        a, b = a.double().cpu(), b.double()
+        return float((a - b).norm() / b.norm())
+    errs = sorted(l2_err(xd.grad.view(members, n, C)[k], xr.grad[k]) for k in range(members))
+    assert errs[len(errs) // 2] <= REL_TOL and errs[-1] <= 5e-2, errs
+    got = dict(model.named_parameters())
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[name].grad is None, name
+        else:
+            assert l2_err(got[name].grad, p.grad) <= 2e-2, name
+    # the per-layer autograd path computes the same gradients
+    model.zero_grad()
+    xd2 = (x if members > 1 else x[0]).to(DEV).requires_grad_()
+    stack_grads = {k: v.grad.clone() for k, v in got.items() if v.grad is not None}
+    model.zero_grad()
+    model.conv_layers(xd2, model.prepare(ei.to(DEV), n)).backward((gout if members > 1 else gout[0]).to(DEV))
+    assert rel_err(xd2.grad, xd.grad) <= 2e-5          # same forward values, same masks: rounding order only
+    for k, v in stack_grads.items():
+        assert rel_err(got[k].grad, v) <= 2e-5, k
+
+
+def test_stack_backward_without_input_grad_and_determinism(ga):
+    m = ga.geodesic_mesh(9, reorder="hilbert")
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(1, 1, 64, 64, 64)).to(DEV)
+    x = torch.randn(m.num_nodes, 64, device=DEV)                       # no grad wrt the input: as in training
+    grads = []
+    for _ in range(2):
+        model.zero_grad()
+        model(x, ei).square().mean().backward()
+        grads.append([p.grad.clone() for p in model.parameters() if p.grad is not None])
+    assert len(grads[0]) == 12 and all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+def test_precision_switch_train_and_eval_agree(ga):
+    """One documented precision rule for both host paths: the per-layer autograd path (train) and the stack
+    launcher (eval) give the same forward values -- bitwise for widths without K5 chains -- in both
+    precisions, on K4 widths and on the K3 + K2 fallbacks; "fp32" is closer to the fp64 oracle than "3xbf16"."""
+    from oracle import gcn_oracle as O
+    m = ga.geodesic_mesh(7, reorder="hilbert")
+    n, ei = m.num_nodes, torch.from_numpy(m.edge_index)
+    for C, H in ((20, 48), (16, 64)):
+        torch.manual_seed(SEED)
+        ref = O.OracleGNNModel(O.OracleGNNConfig(n, n, C, C, H)).double()
+        model = ga.GNNModel(ga.GNNConfig(n, n, C, C, H))
+        model.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        model = model.to(DEV)
+        x = torch.randn(n, C, generator=torch.Generator().manual_seed(SEED))
+        with torch.no_grad():
+            want = ref(x.double(), ei)
+        errs = {}
+        for prec in ("3xbf16", "fp32"):
+            model.set_precision(prec)
+            assert all(c.precision == prec for c in model.modules() if isinstance(c, ga.GCNConv))
+            with torch.no_grad():
+                ev = model(x.to(DEV), ei.to(DEV))                       # stack launcher
+            tr = model.conv_layers(x.to(DEV).requires_grad_(), model.prepare(ei.to(DEV), n)).detach()   # per layer
+            if (C, H) == (20, 48) or prec == "fp32":                    # no K5 chain re-bracketing: bit for bit
+                assert torch.equal(ev, tr), (C, H, prec)
+            else:
+                assert rel_err(ev, tr) <= 2e-5
+            errs[prec] = rel_err(ev, want)
+            assert errs[prec] <= REL_TOL
+        assert errs["fp32"] <= 2e-6 and errs["fp32"] <= errs["3xbf16"]
+    with pytest.raises(ValueError):
+        model.set_precision("bf16")

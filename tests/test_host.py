@@ -227,3 +227,23 @@ def test_edge_features_of_the_forecaster_graphs():
     a, b = edge_features(cell, m.pos, g2m), edge_features(m.pos, cell, m2g)
     assert np.allclose(a[:, 0], b[:, 0]) and np.allclose(a[:, 1:], -b[:, 1:], atol=1e-6)
     assert a[:, 0].max() < 2.0 / 3 + 0.5                       # a corner is close to its cell centre
+
+
+def test_loss_func_is_the_reference_masked_l1():
+    """gwen_amd.loss_func (masked sum, no boolean indexing) == the reference's
+    l1_loss(output[mask], target[mask]) (models_gnn.py:261-265) in value and gradient; an empty mask gives NaN
+    in both."""
+    torch.manual_seed(3)
+    o = torch.randn(50, 7, requires_grad=True)
+    t = torch.randn(50, 7)
+    m = torch.rand(50) < 0.4
+    a = gwen_amd.loss_func(o, t, m)
+    b = torch.nn.functional.l1_loss(o[m], t[m])
+    assert abs(float(a) - float(b)) <= 1e-6
+    ga, = torch.autograd.grad(a, o)
+    gb, = torch.autograd.grad(b, o)
+    assert torch.allclose(ga, gb, atol=1e-8)
+    o3, t3 = torch.randn(3, 50, 7), torch.randn(3, 50, 7)
+    assert abs(float(gwen_amd.loss_func(o3, t3, m)) - float(torch.nn.functional.l1_loss(o3[:, m], t3[:, m]))) <= 1e-6
+    none = torch.zeros(50, dtype=torch.bool)
+    assert torch.isnan(gwen_amd.loss_func(o, t, none)) and torch.isnan(torch.nn.functional.l1_loss(o[none], t[none]))

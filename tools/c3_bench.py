@@ -7,7 +7,7 @@ import torch, gwen_amd
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = "cuda:0"
-mesh = gwen_amd.geodesic_mesh(100, reorder="morton")
+mesh = gwen_amd.geodesic_mesh(100, reorder="hilbert")
 n, e = mesh.num_nodes, mesh.num_edges
 torch.manual_seed(23)
 layers = []

@@ -7,7 +7,7 @@ from gwen_amd import g2m
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = "cuda:0"
-mesh = gwen_amd.geodesic_mesh(100, reorder="morton")
+mesh = gwen_amd.geodesic_mesh(100, reorder="hilbert")
 torch.manual_seed(23)
 model = g2m.GridMeshGridModel(C, H, 4).to(dev).eval()
 graphs = model.prepare(mesh, dev)

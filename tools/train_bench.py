@@ -7,7 +7,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "mesh"
 dev = "cuda:0"
 torch.manual_seed(23)
 if which == "mesh":
-    mesh = gwen_amd.geodesic_mesh(100, reorder="morton")
+    mesh = gwen_amd.geodesic_mesh(100, reorder="hilbert")
     n, c, h = mesh.num_nodes, 64, 64
     ei = torch.from_numpy(mesh.edge_index).to(dev)
 else:
