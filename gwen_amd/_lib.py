@@ -57,6 +57,7 @@ SIGNATURES = {
     "gwen_gcn_prep_rect": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                                   C.c_size_t, _vp]),
     "gwen_gcn_transpose": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "gwen_gcn_transpose_rect": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gwen_gcn_group8_capacity": (_i64, [_i64, _i64]),
     "gwen_gcn_group8": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gwen_checksum_workspace_bytes": (_i64, []),

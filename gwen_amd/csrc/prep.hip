@@ -147,12 +147,13 @@ __device__ inline int32_t row_of_slot(const int32_t *rowptr, int64_t N, int32_t 
   return (int32_t)lo;
 }
 
+// N = rows of the CSR being transposed, NT = rows of its transpose (== N on a square graph)
 __global__ void k_tmark(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                        int64_t N, int64_t cap, int sbits, uint64_t *__restrict__ keys) {
+                        int64_t N, int64_t NT, int64_t cap, int sbits, uint64_t *__restrict__ keys) {
   int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= cap) return;
   int32_t nnz = rowptr[N];
-  uint64_t src = (s < nnz) ? (uint64_t)col[s] : (uint64_t)N;
+  uint64_t src = (s < nnz) ? (uint64_t)col[s] : (uint64_t)NT;
   keys[s] = (src << sbits) | (uint64_t)s;
 }
 
@@ -164,12 +165,12 @@ __global__ void k_trowptr(const uint64_t *__restrict__ ks, int64_t cap, int64_t 
 }
 
 __global__ void k_tfill(const uint64_t *__restrict__ ks, const int32_t *__restrict__ rowptr,
-                        const float *__restrict__ val, int64_t cap, int64_t N, int sbits,
+                        const float *__restrict__ val, int64_t cap, int64_t N, int64_t NT, int sbits,
                         int32_t *__restrict__ t_col, float *__restrict__ t_val) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= cap) return;
   uint64_t k = ks[i];
-  if ((int64_t)(k >> sbits) >= N) return;
+  if ((int64_t)(k >> sbits) >= NT) return;
   int32_t s = (int32_t)(k & ((uint64_t(1) << sbits) - 1));
   t_col[i] = row_of_slot(rowptr, N, s);
   t_val[i] = val[s];
@@ -346,16 +347,16 @@ extern "C" int gwen_gcn_prep_rect(const int64_t *edge_index, const float *edge_w
   return GWEN_OK;
 }
 
-extern "C" int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, const float *val,
-                                  int64_t N, int64_t cap, int32_t *t_rowptr, int32_t *t_col,
-                                  float *t_val, void *workspace, size_t workspace_bytes,
-                                  gwen_stream_t stream_) {
-  if (N < 0 || cap < 0 || !rowptr || !t_rowptr) return GWEN_EINVAL;
-  if (cap >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
+extern "C" int gwen_gcn_transpose_rect(const int32_t *rowptr, const int32_t *col, const float *val,
+                                       int64_t N, int64_t N_t, int64_t cap, int32_t *t_rowptr,
+                                       int32_t *t_col, float *t_val, void *workspace,
+                                       size_t workspace_bytes, gwen_stream_t stream_) {
+  if (N < 0 || N_t < 0 || cap < 0 || !rowptr || !t_rowptr) return GWEN_EINVAL;
+  if (cap >= (int64_t(1) << 31) - 1 || N_t >= (int64_t(1) << 31) - 1) return GWEN_ERANGE;
   if (cap > 0 && (!col || !val || !t_col || !t_val)) return GWEN_EINVAL;
   WsLayout L;
-  int64_t E = cap - N > 0 ? cap - N : 0;
-  int rc = ws_layout(N, E, &L);
+  const int64_t nmax = N > N_t ? N : N_t;
+  int rc = ws_layout(nmax, cap, &L);
   if (rc != GWEN_OK) return rc;
   if (!workspace || workspace_bytes < L.total) return GWEN_ENOSPACE;
   hipStream_t stream = gwen_stream(stream_);
@@ -363,23 +364,31 @@ extern "C" int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, con
   uint64_t *keys_in = reinterpret_cast<uint64_t *>(ws + L.keys_in);
   uint64_t *keys_out = reinterpret_cast<uint64_t *>(ws + L.keys_out);
   const int sbits = bits_for((uint64_t)(cap > 1 ? cap : 2));
-  const int nbits = bits_for((uint64_t)N + 1);
+  const int nbits = bits_for((uint64_t)N_t + 1);
   const uint64_t *ks = keys_in;
   if (cap > 0) {
-    k_tmark<<<blocks_for(cap), kThreads, 0, stream>>>(rowptr, col, N, cap, sbits, keys_in);
+    k_tmark<<<blocks_for(cap), kThreads, 0, stream>>>(rowptr, col, N, N_t, cap, sbits, keys_in);
     GWEN_LAUNCH_CHECK();
     size_t tb = L.temp_bytes;
     GWEN_HIP_CHECK(rocprim::radix_sort_keys(ws + L.temp, tb, keys_in, keys_out, (size_t)cap, 0u,
                                             (unsigned)(sbits + nbits), stream));
     ks = keys_out;
   }
-  k_trowptr<<<blocks_for(N + 1), kThreads, 0, stream>>>(ks, cap, N, sbits, t_rowptr);
+  k_trowptr<<<blocks_for(N_t + 1), kThreads, 0, stream>>>(ks, cap, N_t, sbits, t_rowptr);
   GWEN_LAUNCH_CHECK();
   if (cap > 0) {
-    k_tfill<<<blocks_for(cap), kThreads, 0, stream>>>(ks, rowptr, val, cap, N, sbits, t_col, t_val);
+    k_tfill<<<blocks_for(cap), kThreads, 0, stream>>>(ks, rowptr, val, cap, N, N_t, sbits, t_col, t_val);
     GWEN_LAUNCH_CHECK();
   }
   return GWEN_OK;
+}
+
+extern "C" int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, const float *val,
+                                  int64_t N, int64_t cap, int32_t *t_rowptr, int32_t *t_col,
+                                  float *t_val, void *workspace, size_t workspace_bytes,
+                                  gwen_stream_t stream_) {
+  return gwen_gcn_transpose_rect(rowptr, col, val, N, N, cap, t_rowptr, t_col, t_val, workspace,
+                                 workspace_bytes, stream_);
 }
 
 extern "C" int64_t gwen_gcn_group8_capacity(int64_t N, int64_t cap) {

@@ -16,7 +16,7 @@ the CPU in oracle/interaction_oracle.py):
 
 The grid is the set of triangle centres of the geodesic mesh; every cell is linked with its three
 corner vertices (gwen_amd/g2m.py).  Static embeddings (vm, e_*) depend on the weights only and are
-computed once per ``forward`` / ``rollout`` call.  Inference only.  A leading members axis
+computed once per ``forward`` / ``rollout`` call.  Trainable (``interaction._InteractionNetFunction``).  A leading members axis
 ``[members, N_grid, C]`` runs as ONE launch set over the block-diagonal graph (``ForecastGraphs.batched``).
 """
 from __future__ import annotations
@@ -95,25 +95,30 @@ class InteractionForecaster(nn.Module):
         fs = [g.sort_edges(torch.from_numpy(f).to(device)) for g, f in zip(gs, feats)]
         return ForecastGraphs(*gs, torch.from_numpy(mesh.pos.astype(np.float32)).to(device), *fs)
 
+    @staticmethod
+    def _lin(x: Tensor, m: nn.Linear) -> Tensor:
+        """K3 for inference; torch's own linear (library GEMM, differentiable) when gradients are needed."""
+        if torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad):
+            return nn.functional.linear(x, m.weight, m.bias)
+        return ops.linear(x, m.weight, m.bias, exact=False)
+
     def _static(self, graphs: ForecastGraphs):
-        lin = lambda x, m: ops.linear(x, m.weight, m.bias, exact=False)      # noqa: E731
+        lin = self._lin
         return (lin(graphs.mesh_pos, self.mesh_embed), lin(graphs.f_g2m, self.g2m_edge_embed),
                 lin(graphs.f_mesh, self.mesh_edge_embed), lin(graphs.f_m2g, self.m2g_edge_embed))
 
     def _step(self, grid_x: Tensor, graphs: ForecastGraphs, static) -> Tensor:
         vm, e_g2m, e_m, e_m2g = static
-        vg = ops.linear(grid_x, self.grid_embed.weight, self.grid_embed.bias, exact=False)
+        vg = self._lin(grid_x, self.grid_embed)
         vm, _ = self.encoder(vg, vm, e_g2m, graphs.g2m, update_edges=False)
         for net in self.processor:
             vm, e_m = net(vm, vm, e_m, graphs.mesh)
         vg, _ = self.decoder(vm, vg, e_m2g, graphs.m2g, update_edges=False)
-        return grid_x + ops.linear(vg, self.readout.weight, self.readout.bias, exact=False)
+        return grid_x + self._lin(vg, self.readout)
 
     def forward(self, grid_x: Tensor, graphs: ForecastGraphs) -> Tensor:
         """``grid_x`` [N_grid, C] or [members, N_grid, C] (members share graphs and weights: one launch set
         over the block-diagonal graph)."""
-        if torch.is_grad_enabled() and (grid_x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise RuntimeError("InteractionForecaster is inference-only: call it under torch.no_grad()")
         if grid_x.dim() == 3:
             m = grid_x.size(0)
             gb = graphs.batched(m)

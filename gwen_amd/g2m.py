@@ -13,7 +13,7 @@ the reference to compare with:
 The grid is the set of triangle centres of the geodesic mesh (20 nu^2 cells); every cell is linked to its
 three corner vertices in both directions.  A bipartite layer is one K4 launch (or K3 + K2)
 over a rectangular CSR (gwen_gcn_prep_rect); the rollout feeds each step's grid output back as input.
-Inference only (no autograd through the bipartite layers).
+Trainable: the bipartite layers go through the GCN layer's autograd Function.
 """
 from __future__ import annotations
 
@@ -52,14 +52,9 @@ class BipartiteConv(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x_src: Tensor, graph: GraphCSR, relu: bool = False) -> Tensor:
-        if torch.is_grad_enabled() and (x_src.requires_grad or self.lin.weight.requires_grad):
-            raise RuntimeError("BipartiteConv is inference-only: call it under torch.no_grad()")
-        w, b = self.lin.weight, self.bias
-        if ops.layer_supported(self.in_channels, self.out_channels):
-            return ops.layer_fused(graph, x_src, w, b, relu)                   # one K4 launch
-        if self.out_channels <= self.in_channels:                              # project, then aggregate
-            return ops.propagate(graph, ops.linear(x_src, w, exact=False), b, relu)
-        return ops.linear(ops.propagate(graph, x_src), w, b, relu, exact=False)
+        """The GCN layer's kernels on a rectangular graph, differentiable through the same autograd Function
+        (its backward walks the rectangular transpose: ``GraphCSR.transposed_graph``)."""
+        return ops.gcn_layer(x_src, self.lin.weight, self.bias, graph, relu=relu, order="auto")
 
 
 class GridMeshGridModel(nn.Module):

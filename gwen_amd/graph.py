@@ -49,7 +49,7 @@ class GraphCSR:
     _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
     _dense: Optional[Tensor] = field(default=None, repr=False)
     _tiles: Optional[tuple] = field(default=None, repr=False)
-    _tgrouped: Optional[tuple] = field(default=None, repr=False)
+    _tgraph: Optional["GraphCSR"] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -97,12 +97,7 @@ class GraphCSR:
     def transposed_grouped(self) -> Tuple[Optional[Tensor], Tensor, Tensor]:
         """Grouped layout (gwen_gcn_group8) of the TRANSPOSED CSR: what K4's kernel walks in the backward
         pass (gwen_gcn_layer_bwd_f32).  Built on first use."""
-        if self._tgrouped is None:
-            t_rowptr, t_col, t_val = self.transposed()
-            shadow = GraphCSR(self.num_nodes, self.num_edges, t_rowptr, t_col, t_val, self.eid, self.dis,
-                              self.status)
-            self._tgrouped = _grouped_impl(shadow)
-        return self._tgrouped
+        return self.transposed_graph().grouped()
 
     def dense(self) -> Optional[Tensor]:
         """The graph as a dense padded fp32 matrix for K7 (square graphs of at most 256 nodes: the
@@ -120,25 +115,33 @@ class GraphCSR:
         return self._dense
 
     def transposed(self) -> Tuple[Tensor, Tensor, Tensor]:
-        """CSR by SOURCE node (rowptr, col = target, val) for the backward pass; built on first use."""
-        if self.num_src >= 0:
-            raise RuntimeError("bipartite graphs are inference-only (no transposed structure)")
+        """CSR by SOURCE node (rowptr [source_nodes + 1], col = target, val) for the backward pass; built on
+        first use.  On a bipartite graph the transpose has ``num_src`` rows."""
         if self._transposed is None:
-            n, cap = self.num_nodes, self.num_nodes + self.num_edges
+            n, nt = self.num_nodes, self.source_nodes
+            cap = self.num_edges + (self.num_nodes if self.num_src < 0 else 0)
             dev = self.device
-            t_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            t_rowptr = torch.empty(nt + 1, dtype=torch.int32, device=dev)
             t_col = torch.empty(max(cap, 1) + 8, dtype=torch.int32, device=dev)
             t_val = torch.empty(max(cap, 1) + 8, dtype=torch.float32, device=dev)
-            ws = self._workspace
-            if ws is None:
-                ws = _alloc_workspace(n, self.num_edges, dev)
+            ws = _alloc_workspace(max(n, nt), cap, dev)
             with torch.cuda.device(dev):
-                rc = _lib.lib().gwen_gcn_transpose(
-                    _ptr(self.rowptr), _ptr(self.col), _ptr(self.val), n, cap, _ptr(t_rowptr),
+                rc = _lib.lib().gwen_gcn_transpose_rect(
+                    _ptr(self.rowptr), _ptr(self.col), _ptr(self.val), n, nt, cap, _ptr(t_rowptr),
                     _ptr(t_col), _ptr(t_val), _ptr(ws), ws.numel(), _stream(dev))
-            _lib.check(rc, "gwen_gcn_transpose")
+            _lib.check(rc, "gwen_gcn_transpose_rect")
             self._transposed = (t_rowptr, t_col, t_val)
         return self._transposed
+
+    def transposed_graph(self) -> "GraphCSR":
+        """The transpose as a GraphCSR of its own (rows = this graph's source nodes, columns = its target
+        rows): what K2 / K4 walk in the backward pass.  Shares the derived-layout caches of a GraphCSR."""
+        if self._tgraph is None:
+            t_rowptr, t_col, t_val = self.transposed()
+            self._tgraph = GraphCSR(self.source_nodes, self.num_edges, t_rowptr, t_col, t_val, self.eid,
+                                    self.dis, self.status,
+                                    num_src=self.num_nodes if self.num_src >= 0 else -1)
+        return self._tgraph
 
 
 def _grouped_impl(g: "GraphCSR") -> Tuple[Tensor, Tensor, Tensor]:

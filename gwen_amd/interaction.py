@@ -8,7 +8,7 @@ oracle/interaction_oracle.py, PARITY UNPINNED):
     agg_d = sum / mean of m_e over the in-edges of d
     x'_d  = x_dst_d + MLP_n([x_dst_d, agg_d]) ,   e' = e + m_e
 
-How it runs (3 launches on a square graph, 4 on a bipartite one; inference only):
+How it runs (3 launches on a square graph, 4 on a bipartite one; training: _InteractionNetFunction):
   * the node halves of both first layers are projected per NODE, not per edge, by ONE K3 launch with the
     three weights stacked (3xbf16): [Ps | Pd | Q] = x [W1[:, F:2F]; W1[:, 2F:]; W3[:, :F]]^T + [0, b1, b3]
     (sources projected apart when x_src is not x_dst); K6 reads them as strided column blocks;
@@ -175,7 +175,8 @@ def _mlp(fin: int, f: int, act: str) -> nn.Sequential:
 
 class InteractionNet(nn.Module):
     """``forward(x_src, x_dst, e, graph) -> (x_dst', e')``; parameters ``edge_mlp.{0,2}.{weight,bias}``
-    ([F,3F] / [F,F]) and ``node_mlp.{0,2}.{weight,bias}`` ([F,2F] / [F,F]).  Inference only."""
+    ([F,3F] / [F,F]) and ``node_mlp.{0,2}.{weight,bias}`` ([F,2F] / [F,F]).  Forward on K6; when gradients are
+    needed the backward recomputes the block in torch device ops (``_InteractionNetFunction``)."""
 
     def __init__(self, channels: int, activation: str = "silu", aggr: str = "sum"):
         super().__init__()
@@ -209,12 +210,18 @@ class InteractionNet(nn.Module):
 
     def forward(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph,
                 update_edges: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (x_src, x_dst, e, *self.parameters())):
-            raise RuntimeError("InteractionNet is inference-only: call it under torch.no_grad()")
         f = self.channels
         if x_src.shape != (graph.num_src, f) or x_dst.shape != (graph.num_dst, f) or \
                 e.shape != (graph.num_edges, f):
             raise ValueError("x_src / x_dst / e do not match the graph and the channel count")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (x_src, x_dst, e, *self.parameters())):
+            return _InteractionNetFunction.apply(self, graph, update_edges, x_src is x_dst, x_src, x_dst, e,
+                                                 *self.parameters())
+        return self._forward_k6(x_src, x_dst, e, graph, update_edges)
+
+    def _forward_k6(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph,
+                    update_edges: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+        f = self.channels
         we, wa, wn, bn = self._weight_blocks()
         if x_src is x_dst:                                   # mesh -> mesh: one launch, [N, 3F]
             p = ops.linear(x_dst, wn, bn, exact=False)
@@ -229,3 +236,66 @@ class InteractionNet(nn.Module):
         x_new, _ = mlp2(agg, wa, self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
                         res=x_dst, act=self.activation)
         return x_new, e_new
+
+    def _forward_torch(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph, params):
+        """The block in differentiable torch device ops (library GEMMs, index_select, index_add_) on the
+        graph's STORED edge order: what the backward pass differentiates (recomputed, see
+        ``_InteractionNetFunction``).  ``params`` in ``self.parameters()`` order."""
+        w1, b1, w2, b2, w3, b3, w4, b4 = params
+        f = self.channels
+        act = {"none": lambda v: v, "relu": torch.relu, "silu": torch.nn.functional.silu}[self.activation]
+        src, dst = graph.src.long(), graph.dst.long()
+        pre = e @ w1[:, :f].t() + (x_src @ w1[:, f:2 * f].t()).index_select(0, src) + \
+            (x_dst @ w1[:, 2 * f:].t() + b1).index_select(0, dst)
+        m = act(pre) @ w2.t() + b2
+        agg = torch.zeros_like(x_dst).index_add_(0, dst, m)
+        if self.aggr == "mean":
+            deg = (graph.rowptr[1:] - graph.rowptr[:-1]).to(m.dtype).clamp(min=1).view(-1, 1)
+            agg = agg / deg
+        x_new = x_dst + act(x_dst @ w3[:, :f].t() + agg @ w3[:, f:].t() + b3) @ w4.t() + b4
+        return x_new, e + m
+
+
+class _InteractionNetFunction(torch.autograd.Function):
+    """Training through an InteractionNet block: the forward runs on K6 (no intermediate is kept), the
+    backward RECOMPUTES the block in torch device ops under autograd (``InteractionNet._forward_torch``:
+    rocBLAS GEMMs, index_select, index_add_) and differentiates that.  A correctness-first path for the
+    BUILD-DEFINED f2 models (the reference has no edge MLP): no hand-written backward kernels yet, the
+    scatter-adds of the backward use float atomics (not bitwise reproducible), and the recomputation costs
+    one extra forward in library kernels."""
+
+    @staticmethod
+    def forward(ctx, net, graph, update_edges, same, x_src, x_dst, e, *params):
+        with torch.no_grad():
+            x_new, e_new = net._forward_k6(x_dst if same else x_src, x_dst, e, graph, update_edges)
+        ctx.net, ctx.graph, ctx.update_edges, ctx.same = net, graph, update_edges, same
+        ctx.save_for_backward(x_src, x_dst, e, *params)
+        if e_new is None:
+            e_new = e.new_empty(0)
+            ctx.mark_non_differentiable(e_new)
+        return x_new, e_new
+
+    @staticmethod
+    def backward(ctx, gx, ge):
+        x_src, x_dst, e, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad[4:]
+        with torch.enable_grad():
+            xd = x_dst.detach().requires_grad_(need[1] or (ctx.same and need[0]))
+            xs = xd if ctx.same else x_src.detach().requires_grad_(need[0])
+            ee = e.detach().requires_grad_(need[2])
+            ps = [p.detach().requires_grad_(n) for p, n in zip(params, need[3:])]
+            x_new, e_new = ctx.net._forward_torch(xs, xd, ee, ctx.graph, ps)
+            outs, gouts = [x_new], [gx]
+            if ctx.update_edges and ge is not None:
+                outs.append(e_new); gouts.append(ge)
+            wanted = [t for t in ([xd] if ctx.same else [xs, xd]) + [ee] + ps if t.requires_grad]
+            grads = torch.autograd.grad(outs, wanted, gouts, allow_unused=True) if wanted else []
+        it = iter(grads)
+        take = lambda t: next(it) if t.requires_grad else None          # noqa: E731
+        if ctx.same:           # x_src is x_dst: one tensor in two argument slots -- its gradient is reported once
+            g_xs, g_xd = None, take(xd)
+        else:
+            g_xs, g_xd = take(xs), take(xd)
+        g_e = take(ee)
+        g_ps = [take(p) for p in ps]
+        return (None, None, None, None, g_xs, g_xd, g_e, *g_ps)

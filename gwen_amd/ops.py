@@ -38,12 +38,14 @@ def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: b
     h = h.contiguous()
     m, n_src, f = _rows2d(h)
     n = graph.num_nodes
-    if n_src != graph.source_nodes:
+    if not transposed and n_src != graph.source_nodes:
         raise ValueError(f"h has {n_src} rows but the graph has {graph.source_nodes} source nodes")
-    if transposed:
-        rowptr, col, val = graph.transposed()
-    else:
-        rowptr, col, val = graph.rowptr, graph.col, graph.val
+    if transposed:                        # A^T h: rows = this graph's sources, h has one row per target
+        graph = graph.transposed_graph()
+        n = graph.num_nodes
+        if n_src != graph.source_nodes:
+            raise ValueError(f"h has {n_src} rows but the transposed graph has {graph.source_nodes} sources")
+    rowptr, col, val = graph.rowptr, graph.col, graph.val
     if bias is not None:
         _require(bias, "bias")
         bias = bias.contiguous()

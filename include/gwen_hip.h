@@ -74,6 +74,11 @@ int gwen_gcn_prep_rect(const int64_t *edge_index, const float *edge_weight, int6
 int gwen_gcn_transpose(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
                        int64_t cap, int32_t *t_rowptr, int32_t *t_col, float *t_val,
                        void *workspace, size_t workspace_bytes, gwen_stream_t stream);
+/* The same for a rectangular CSR (gwen_gcn_prep_rect: N target rows, columns in [0, N_t)): the transpose
+ * has N_t rows (t_rowptr [N_t + 1]).  workspace: gwen_gcn_prep_workspace_bytes(max(N, N_t), cap). */
+int gwen_gcn_transpose_rect(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
+                            int64_t N_t, int64_t cap, int32_t *t_rowptr, int32_t *t_col, float *t_val,
+                            void *workspace, size_t workspace_bytes, gwen_stream_t stream);
 
 /* Grouped layout of a prepared graph for K4: every row padded to a whole number of 8-entry groups
  * (padding entries carry weight 0 and the column of the row's first entry), so the kernel reads

@@ -181,8 +181,8 @@ def test_rejects_misuse(ga):
     ns, nd, ei = _graphs(ga)["one_edge"]
     graph = interaction_graph(ei.to(DEV), ns, nd)
     net = InteractionNet(64).to(DEV)
-    with pytest.raises(RuntimeError):
-        net(torch.randn(3, 64, device=DEV), torch.randn(3, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
+    with pytest.raises(ValueError):                              # shapes are checked before anything runs
+        net(torch.randn(ns + 1, 64, device=DEV), torch.randn(nd, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
     with torch.no_grad(), pytest.raises(ValueError):
         net(torch.randn(4, 64, device=DEV), torch.randn(3, 64, device=DEV), torch.randn(1, 64, device=DEV), graph)
 
@@ -308,3 +308,63 @@ def test_interaction_block_on_random_bipartite_graphs(ga, seed):
         got_x, got_e = net(xs.to(DEV), xd.to(DEV), graph.sort_edges(ef.to(DEV)), graph)
     assert rel_err(got_x, want_x) <= REL_TOL
     assert rel_err(graph.unsort_edges(got_e), want_e) <= REL_TOL
+
+
+@pytest.mark.parametrize("F,act,aggr,bip", [(32, "silu", "sum", False), (64, "relu", "mean", True),
+                                           (128, "silu", "sum", True), (64, "none", "sum", False)])
+def test_interaction_block_backward_vs_oracle_autograd(ga, F, act, aggr, bip):
+    """Training through a block (forward on K6, backward by recomputation in torch device ops): every
+    gradient -- x_src, x_dst, e, the 8 parameters -- against torch autograd on the fp64 CPU oracle."""
+    from gwen_amd.interaction import InteractionNet, interaction_graph
+    from oracle import interaction_oracle as IO
+    rng = np.random.default_rng(77 + F)
+    ns, nd, e_ = (150, 210, 1300) if bip else (180, 180, 1100)
+    src, dst = rng.integers(0, ns, size=e_), rng.integers(0, nd, size=e_)
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    torch.manual_seed(SEED + F)
+    net = InteractionNet(F, act, aggr)
+    g = torch.Generator().manual_seed(SEED)
+    xs, xd, ef = torch.randn(ns, F, generator=g), torch.randn(nd, F, generator=g), torch.randn(e_, F, generator=g)
+    gxo, geo = torch.randn(nd, F, generator=g), torch.randn(e_, F, generator=g)
+    sd = {k: v.double().clone().requires_grad_() for k, v in net.state_dict().items()}
+    xs64, xd64, ef64 = xs.double().requires_grad_(), xd.double().requires_grad_(), ef.double().requires_grad_()
+    wx, we = IO.interaction(xd64 if not bip else xs64, xd64, ef64, ei, sd, act, aggr)
+    (wx * gxo.double()).sum().add((we * geo.double()).sum()).backward()
+    graph = interaction_graph(ei.to(DEV), ns, nd)
+    net = net.to(DEV)
+    xsd, xdd = xs.to(DEV).requires_grad_(), xd.to(DEV).requires_grad_()
+    efd = graph.sort_edges(ef.to(DEV)).detach().requires_grad_()
+    gx, ge = net(xdd if not bip else xsd, xdd, efd, graph)
+    ((gx * gxo.to(DEV)).sum() + (ge * graph.sort_edges(geo.to(DEV))).sum()).backward()
+    assert rel_err(gx.detach(), wx.detach()) <= REL_TOL
+    tol = 2e-4                                                  # fp32 library GEMMs + atomics vs fp64
+    assert rel_err(xdd.grad, xd64.grad) <= tol
+    if bip:
+        assert rel_err(xsd.grad, xs64.grad) <= tol
+    assert rel_err(graph.unsort_edges(efd.grad), ef64.grad) <= tol
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, sd[k].grad) <= tol, k
+
+
+def test_forecaster_training_step(ga):
+    """The c5-shaped model trains: gradients reach every parameter and Adam lowers the loss."""
+    from gwen_amd.forecaster import InteractionForecaster
+    m = ga.geodesic_mesh(4, reorder="hilbert")
+    torch.manual_seed(SEED)
+    model = InteractionForecaster(6, 32, 2).to(DEV)
+    graphs = model.prepare(m, DEV)
+    x = torch.randn(m.faces.shape[0], 6, device=DEV)
+    y = torch.randn(m.faces.shape[0], 6, device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = (model(x, graphs) - y).square().mean()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+    with torch.no_grad():                                       # inference path unchanged by training mode
+        a = model(x, graphs)
+    assert torch.isfinite(a).all()
