@@ -62,6 +62,8 @@ SIGNATURES = {
     "gwen_gcn_group8": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gwen_checksum_workspace_bytes": (_i64, []),
     "gwen_checksum128": (_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
+    "gwen_gcn_segments_capacity": (_i64, [_i64, _i64, _i64]),
+    "gwen_gcn_segments": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gwen_gcn_propagate_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                       _i64, _i64, _int, _vp]),
     "gwen_gcn_linear_workspace_floats": (_i64, [_i64, _i64, _i64]),

@@ -188,6 +188,35 @@ __global__ void k_glen(const int32_t *__restrict__ rowptr, int64_t N, int32_t *_
 
 __global__ void k_set1(int32_t *p) { *p = 1; }
 
+// ---- row segmentation (long rows): row r of length len is cut into max(1, ceil(len / S)) segments -----
+__global__ void k_segcount(const int32_t *__restrict__ rowptr, int64_t N, int32_t S,
+                           int32_t *__restrict__ cnt, int32_t *__restrict__ status) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r > N) return;
+  int32_t c = 0;
+  if (r < N) {
+    const int32_t len = rowptr[r + 1] - rowptr[r];
+    c = len <= S ? 1 : (len + S - 1) / S;
+    atomicMax(&status[0], c);
+    atomicMax(&status[1], len);
+  }
+  cnt[r] = c;
+}
+
+__global__ void k_segfill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ rowptr2,
+                          int64_t N, int32_t S, int32_t *__restrict__ seg_rowptr,
+                          int32_t *__restrict__ col2, float *__restrict__ val2) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r > N) return;
+  if (r == N) { seg_rowptr[rowptr2[N]] = rowptr[N]; return; }
+  const int32_t a = rowptr[r], k0 = rowptr2[r], k1 = rowptr2[r + 1];
+  for (int32_t k = k0; k < k1; ++k) {
+    seg_rowptr[k] = a + (k - k0) * S;
+    col2[k] = k;
+    val2[k] = 1.0f;
+  }
+}
+
 // 8 lanes per row copy its entries and append the padding (weight 0, column of the row's first
 // entry: a row that is already part of the sum); lane group N writes the all-zero null group.
 __global__ void k_gfill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -421,6 +450,37 @@ extern "C" int gwen_gcn_group8(const int32_t *rowptr, const int32_t *col, const 
                                          rocprim::plus<int32_t>(), stream));
   k_gfill<<<blocks_for((N + 1) * 8), kThreads, 0, stream>>>(rowptr, col, val, g_rowptr, N, g_col,
                                                             g_val);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+extern "C" int64_t gwen_gcn_segments_capacity(int64_t N, int64_t nnz, int64_t S) {
+  if (N < 0 || nnz < 0 || S < 1) return GWEN_EINVAL;
+  return N + nnz / S + 1;                        // every row at least one segment, a long row len / S + 1
+}
+
+extern "C" int gwen_gcn_segments(const int32_t *rowptr, int64_t N, int64_t S, int32_t *rowptr2,
+                                 int32_t *seg_rowptr, int32_t *col2, float *val2, int32_t *status,
+                                 void *workspace, size_t workspace_bytes, gwen_stream_t stream_) {
+  if (N < 0 || S < 1 || S >= (int64_t(1) << 30) || !rowptr || !rowptr2 || !seg_rowptr || !col2 || !val2 ||
+      !status)
+    return GWEN_EINVAL;
+  if (N >= (int64_t(1) << 31) - 2) return GWEN_ERANGE;
+  hipStream_t stream = gwen_stream(stream_);
+  const size_t cnt_bytes = gwen_align_up(sizeof(int32_t) * (size_t)(N + 1), 256);
+  size_t tb = 0;
+  GWEN_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, (int32_t *)nullptr, (int32_t *)nullptr, 0,
+                                         (size_t)(N + 1), rocprim::plus<int32_t>(), stream));
+  if (!workspace || workspace_bytes < cnt_bytes + tb) return GWEN_ENOSPACE;
+  int32_t *cnt = static_cast<int32_t *>(workspace);
+  void *temp = static_cast<char *>(workspace) + cnt_bytes;
+  GWEN_HIP_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), stream));
+  k_segcount<<<blocks_for(N + 1), kThreads, 0, stream>>>(rowptr, N, (int32_t)S, cnt, status);
+  GWEN_LAUNCH_CHECK();
+  GWEN_HIP_CHECK(rocprim::exclusive_scan(temp, tb, cnt, rowptr2, 0, (size_t)(N + 1),
+                                         rocprim::plus<int32_t>(), stream));
+  k_segfill<<<blocks_for(N + 1), kThreads, 0, stream>>>(rowptr, rowptr2, N, (int32_t)S, seg_rowptr, col2,
+                                                        val2);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }

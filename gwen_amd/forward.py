@@ -136,6 +136,10 @@ class StackForward:
         self._small = graph.dense() is not None and all(
             d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, d.fin, d.fout)
             for d in self.desc)
+        # long rows beyond K7's graphs: per-layer K3 + segmented K2 (ops.propagate) instead of the C launcher,
+        # whose fused kernels walk a row serially
+        self._long = (not self._small) and graph.long_row_levels() is not None
+        self._layers = list(layers)
         self._scratch: Optional[Tensor] = None
         self._scratch_key = None
         self._gd = None
@@ -195,6 +199,23 @@ class StackForward:
         n = self.graph.num_nodes
         if x.size(-2) != n or x.size(-1) != self.fin:
             raise ValueError(f"x is {tuple(x.shape)}, expected [..., {n}, {self.fin}]")
+        if self._long:
+            from . import ops
+            cur = x
+            for i, (w, b, relu, order) in enumerate(self._layers):
+                exact = order != "auto"
+                if w.size(1) < w.size(0):                      # gather at the narrower width
+                    cur = ops.linear(ops.propagate(self.graph, cur), w.detach(), None if b is None else b.detach(),
+                                     relu, exact=exact)
+                else:
+                    cur = ops.propagate(self.graph, ops.linear(cur, w.detach(), exact=exact),
+                                        None if b is None else b.detach(), relu)
+                if acts is not None:
+                    acts[i].copy_(cur)
+            if out is not None and acts is None:
+                out.copy_(cur)
+                return out
+            return cur if acts is None else acts[-1]
         dev = x.device
         acts_arr = None
         if acts is not None:

@@ -50,6 +50,7 @@ class GraphCSR:
     _dense: Optional[Tensor] = field(default=None, repr=False)
     _tiles: Optional[tuple] = field(default=None, repr=False)
     _tgraph: Optional["GraphCSR"] = field(default=None, repr=False)
+    _levels: Optional[tuple] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -98,6 +99,46 @@ class GraphCSR:
         """Grouped layout (gwen_gcn_group8) of the TRANSPOSED CSR: what K4's kernel walks in the backward
         pass (gwen_gcn_layer_bwd_f32).  Built on first use."""
         return self.transposed_graph().grouped()
+
+    def long_row_levels(self, seg: int = 32, threshold: int = 256):
+        """For graphs with LONG rows (some row beyond ``threshold`` entries -- the reference's member graphs,
+        rows of at most ~150, stay on the sequential, bit-reproducing path): the chain of CSRs that computes
+        the propagate edge-parallel (gwen_gcn_segments) -- ``[(rowptr, col, val, rows, cols), ...]``, applied
+        first to last: partial sums per ``seg``-entry segment, then the sums of each row's partials in segment
+        order (segmented again while a row still has more than ``seg`` partials).  ``None`` when no row is
+        long (plain K2).  Built on first use; one read-back per level, once per graph."""
+        if self._levels is None:
+            L = _lib.lib()
+            dev = self.device
+            levels = []
+            rowptr, col, val = self.rowptr, self.col, self.val
+            n, cols = self.num_nodes, self.source_nodes
+            nnz = self.num_edges + (self.num_nodes if self.num_src < 0 else 0)
+            first = True
+            while n > 0:
+                cap = int(L.gwen_gcn_segments_capacity(n, nnz, seg))
+                rowptr2 = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                seg_rowptr = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+                col2 = torch.empty(cap + 8, dtype=torch.int32, device=dev)
+                val2 = torch.empty(cap + 8, dtype=torch.float32, device=dev)
+                st = torch.empty(2, dtype=torch.int32, device=dev)
+                ws = _alloc_workspace(n, 0, dev)
+                with torch.cuda.device(dev):
+                    rc = L.gwen_gcn_segments(_ptr(rowptr), n, seg, _ptr(rowptr2), _ptr(seg_rowptr), _ptr(col2),
+                                             _ptr(val2), _ptr(st), _ptr(ws), ws.numel(), _stream(dev))
+                _lib.check(rc, "gwen_gcn_segments")
+                max_segs, max_len = (int(v) for v in st.tolist())
+                if first and max_len <= threshold:
+                    break                                           # no long row: plain K2
+                first = False
+                n_seg = int(rowptr2[-1].item())
+                levels.append((seg_rowptr[: n_seg + 1], col, val, n_seg, cols))      # partial sums per segment
+                if max_segs <= seg:
+                    levels.append((rowptr2, col2, val2, n, n_seg))                   # rows = sums of their partials
+                    break
+                rowptr, col, val, cols, nnz = rowptr2, col2, val2, n_seg, n_seg      # segment the combine again
+            self._levels = (levels if levels else None,)
+        return self._levels[0]
 
     def dense(self) -> Optional[Tensor]:
         """The graph as a dense padded fp32 matrix for K7 (square graphs of at most 256 nodes: the

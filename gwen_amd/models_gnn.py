@@ -165,7 +165,8 @@ class GNNModel(nn.Module):
         if needs_grad:
             # training: the whole stack as one autograd node (one host call per direction) on graphs beyond
             # K7's size; the per-layer autograd Functions on the reference's small member graphs
-            if edge_index.dense() is None and all(b is not None for _, b, _, _ in self.stack()):
+            if edge_index.dense() is None and edge_index.long_row_levels() is None and \
+                    all(b is not None for _, b, _, _ in self.stack()):
                 return stack_apply(x, edge_index, self.stack())
             return self.conv_layers(x, edge_index)
         # inference: the whole stack from one host call (gwen_gnn_forward_f32)

@@ -45,18 +45,25 @@ def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: b
         n = graph.num_nodes
         if n_src != graph.source_nodes:
             raise ValueError(f"h has {n_src} rows but the transposed graph has {graph.source_nodes} sources")
-    rowptr, col, val = graph.rowptr, graph.col, graph.val
     if bias is not None:
         _require(bias, "bias")
         bias = bias.contiguous()
-    out = torch.empty(*h.shape[:-2], n, f, dtype=torch.float32, device=h.device)
     dev = h.device
-    with torch.cuda.device(dev):
-        rc = _lib.lib().gwen_gcn_propagate_f32(
-            _ptr(rowptr), _ptr(col), _ptr(val), _ptr(h), _ptr(bias), _ptr(out), n, f, f, f, m,
-            n_src * f, n * f, int(relu), _stream(dev))
-    _lib.check(rc, "gwen_gcn_propagate_f32")
-    return out
+    # long rows (hub nodes, complete graphs beyond K7's 256 nodes): the same kernel over the segment chain --
+    # every 32-entry segment summed by its own lane group, then each row's partial sums in segment order
+    levels = graph.long_row_levels()
+    chain = levels if levels is not None else [(graph.rowptr, graph.col, graph.val, n, n_src)]
+    cur = h
+    for k, (rowptr, col, val, rows, cols) in enumerate(chain):
+        last = k + 1 == len(chain)
+        out = torch.empty(*h.shape[:-2], rows, f, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gwen_gcn_propagate_f32(
+                _ptr(rowptr), _ptr(col), _ptr(val), _ptr(cur), _ptr(bias) if last else None, _ptr(out), rows, f,
+                f, f, m, cols * f, rows * f, int(relu and last), _stream(dev))
+        _lib.check(rc, "gwen_gcn_propagate_f32")
+        cur = out
+    return cur
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
@@ -280,6 +287,9 @@ class GCNLayerFunction(torch.autograd.Function):
         if order == "auto":
             if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout):
                 order = "small"              # K7: the reference's member graphs (<= 256 nodes)
+            elif graph.long_row_levels() is not None:
+                # rows far beyond 8 entries: the fused kernels walk a row serially, the segment chain does not
+                order = "aggregate_first" if fin < fout else "transform_first"
             elif wide_preferred(graph, x, fin, fout):
                 order = "wide"               # K8: K4's arithmetic, tile-staged (same backward)
             elif layer_supported(fin, fout):

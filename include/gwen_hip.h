@@ -103,6 +103,23 @@ int64_t gwen_checksum_workspace_bytes(void);
 int gwen_checksum128(const void *data, int64_t bytes, uint64_t *out, void *workspace,
                      int64_t workspace_bytes, gwen_stream_t stream);
 
+/* Row segmentation for LONG rows (graphs beyond K7's 256 nodes whose rows are much longer than the 8 entries
+ * one lane group gathers per round trip: complete graphs over more than 256 members, hub nodes).  Row r of
+ * the CSR (length len) is cut into max(1, ceil(len / S)) segments of S entries:
+ *     seg_rowptr int32 [n_seg + 1]   a REFINEMENT of rowptr over the same col / val arrays: K2 on
+ *                                    (seg_rowptr, col, val) gives one partial sum per segment, every segment
+ *                                    summed in stored order by its own lane group (edge-parallel);
+ *     rowptr2 [N + 1], col2 = 0 .. n_seg - 1, val2 = 1   the CSR that adds each row's partial sums in
+ *                                    segment order: K2 on it (bias / ReLU there) finishes the row.
+ * Deterministic (fixed order, no atomics); differs from K2's sequential sum by rounding order only.
+ * rowptr2 itself may be segmented again when a row has more than S segments.
+ * status int32 [2]: [0] = most segments of a row, [1] = longest row.  n_seg = rowptr2[N] <=
+ * gwen_gcn_segments_capacity(N, nnz, S).  workspace: gwen_gcn_prep_workspace_bytes(N, 0) bytes. */
+int64_t gwen_gcn_segments_capacity(int64_t N, int64_t nnz, int64_t S);
+int gwen_gcn_segments(const int32_t *rowptr, int64_t N, int64_t S, int32_t *rowptr2, int32_t *seg_rowptr,
+                      int32_t *col2, float *val2, int32_t *status, void *workspace,
+                      size_t workspace_bytes, gwen_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  fused propagate == MessagePassing.propagate (message w~ * x_j, aggregate add at target)
  *     + bias add (GCNConv.forward) + torch.relu (/root/reference/src/gwen/models_gnn.py:147-149,

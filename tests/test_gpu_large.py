@@ -122,3 +122,77 @@ def test_fused_layer_block_sizes_near_one_resident_round(ga, cref, nu, fin, fout
     got = ops.layer_fused(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
     assert rel_err(got, want) <= 2e-5
     assert torch.equal(got, ops.layer_fused(g, x.to(DEV), w.to(DEV), b.to(DEV), relu=True))
+
+
+def test_segment_chain_structure(ga):
+    """gwen_gcn_segments: seg_rowptr refines rowptr in steps of 32 entries, rowptr2 counts each row's
+    segments, the combine CSR is the identity pattern with unit weights; short-row graphs get no chain."""
+    m = ga.geodesic_mesh(5)
+    assert ga.prepare_graph(torch.from_numpy(m.edge_index).to(DEV), m.num_nodes).long_row_levels() is None
+    assert ga.prepare_graph(torch.from_numpy(ga.complete_graph(150)).to(DEV), 150).long_row_levels() is None
+    n = 50001
+    ei = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)]).to(DEV)      # one row of 50 001
+    g = ga.prepare_graph(ei, n)
+    lv = g.long_row_levels()
+    assert lv is not None and len(lv) == 4            # 50 001 -> 1563 partials -> 49 -> 2 -> 1
+    rowptr = g.rowptr.cpu().numpy().astype(np.int64)
+    seg_rowptr, col, val, n_seg, cols = lv[0]
+    sr = seg_rowptr.cpu().numpy().astype(np.int64)
+    assert cols == n and n_seg == len(sr) - 1 and sr[0] == 0 and sr[-1] == rowptr[-1]
+    assert set(rowptr.tolist()) <= set(sr.tolist()) and np.diff(sr).max() <= 32 and np.diff(sr).min() >= 1
+    assert n_seg == (n - 1) + (50001 + 31) // 32
+    rows_of_last = lv[-1][3]
+    assert rows_of_last == n
+    for (rp, c, v, rows, cols_), (_, _, _, rows_prev, _) in zip(lv[1:], lv[:-1]):
+        assert cols_ == rows_prev
+        k = int(rp[-1])
+        assert torch.equal(c[:k].cpu(), torch.arange(k, dtype=torch.int32)) and bool((v[:k] == 1).all())
+
+
+@pytest.mark.parametrize("case", ["K1000", "star", "hubs"])
+def test_long_rows_edge_parallel_vs_oracle(ga, cref, case):
+    """Rows far beyond 8 entries on graphs beyond K7's 256 nodes: the segment chain (32-entry segments summed
+    by their own lane groups, partial sums added in segment order) against the C oracle; deterministic."""
+    g = torch.Generator().manual_seed(SEED)
+    if case == "K1000":
+        n = 1000
+        ei = torch.from_numpy(ga.complete_graph(n))
+    elif case == "star":
+        n = 50001
+        ei = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)])
+    else:                                              # a mesh plus five hubs that every node points at
+        m = ga.geodesic_mesh(20)
+        n = m.num_nodes
+        hubs = torch.randint(0, n, (5,), generator=g)
+        extra = torch.stack([torch.arange(n).repeat(5), hubs.repeat_interleave(n)])
+        ei = torch.cat([torch.from_numpy(m.edge_index), extra], 1)
+    for fin, fout in ((64, 32), (32, 64), (20, 20)):
+        x = torch.randn(n, fin, generator=g)
+        w, b = make_params(fin, fout)
+        ref = cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True)
+        conv = ga.GCNConv(fin, fout).to(DEV)
+        with torch.no_grad():
+            conv.lin.weight.copy_(w); conv.bias.copy_(b)
+            graph = ga.prepare_graph(ei.to(DEV), n)
+            assert graph.long_row_levels() is not None
+            got = conv(x.to(DEV), graph, relu=True)
+            assert torch.equal(got, conv(x.to(DEV), graph, relu=True))
+        assert rel_err(got, ref) <= 2e-5, (case, fin, fout)
+    # the whole model (inference through StackForward's long-row path, training through the per-layer path)
+    from oracle import gcn_oracle as O
+    if case != "star":
+        torch.manual_seed(SEED)
+        refm = O.OracleGNNModel(O.OracleGNNConfig(n, n, 16, 16, 32))
+        model = ga.GNNModel(ga.GNNConfig(n, n, 16, 16, 32))
+        model.load_state_dict(refm.state_dict())
+        model = model.to(DEV)
+        x = torch.randn(n, 16, generator=g)
+        with torch.no_grad():
+            want = refm(x, ei)
+            got = model(x.to(DEV), ei.to(DEV))
+        assert rel_err(got, want) <= REL_TOL
+        xd = x.to(DEV).requires_grad_()
+        model(xd, ei.to(DEV)).sum().backward()
+        xr = x.clone().requires_grad_()
+        refm(xr, ei).sum().backward()
+        assert float((xd.grad.cpu().double() - xr.grad.double()).norm() / xr.grad.double().norm()) <= 1e-3
