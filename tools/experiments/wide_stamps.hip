@@ -16,12 +16,15 @@
 //   * contracts the 64 x 64 chunk with W on the matrix cores (3xbf16, fp32 accumulate, as K4) while the
 //     DMA of the chunk after next is in flight and the next chunk is being aggregated;
 //   * adds bias / ReLU and stores after the last chunk.
-// One 8-wave block per CU walks its tiles persistently; ONE barrier per 64-feature chunk:
-//     top(s):  s_waitcnt vmcnt(0) (DMA of chunk s+1 landed), barrier
-//              [stores of the tile that finished in chunk s-1]
-//              issue DMA(s+2) -> stage[s % 2]          (free: aggregate(s) is behind the barrier)
-//              aggregate(s+1): stage[(s+1) % 2] -> A[(s+1) % 2]
-//              mfma(s):        A[s % 2] x W[:, chunk]  -> accumulators
+// One block per CU (16 waves; 8 at Fin = 256, where W alone takes 128 registers per wave) walks its tiles
+// persistently; ONE barrier per 64-feature chunk ("step"):
+//     [scalar loads of the row ids of chunk s+D+1]
+//     s_waitcnt vmcnt(n): DMA of chunk s+1 landed;  barrier
+//     2 x (row tiles per wave) regions, each: a share of the step's memory instructions -- the DMAs of chunk
+//     s+D+1 -> stage[s % (D+1)] and the stores of the tile finished in step s-1 --, the LDS reads of a share of
+//     aggregate(s+1), one (row tile, k-step) unit of mfma(s), that share's VALU work woven behind the MFMAs.
+// D = 2 chunks of DMA in flight when the graph's unions stay within 128 rows (three 32 KB stage buffers:
+// the cube-sphere Hilbert node order keeps the nu = 100 mesh at <= 121), D = 1 up to 192 rows (two 48 KB buffers).
 // The DMAs are issued by inline asm, so hipcc neither counts nor drains them (cdna_hip_programming.md
 // section 5 "Pipelining across barriers"); every other global read of the loop is a scalar load (the union
 // rows of the tile) and the only vector-memory instructions hipcc sees are the output stores.
@@ -32,6 +35,7 @@
 // sequence) -- tests compare the two bitwise.
 #include "../../gwen_amd/csrc/common.h"
 #include <type_traits>
+#include <cstdlib>
 
 #ifndef WEAVE_VALU
 #define WEAVE_VALU 2
@@ -106,13 +110,12 @@ __device__ inline void wait_vmcnt(int n) {
 // D = chunks of DMA in flight behind the one being aggregated: D = 2 needs unions of at most 128 rows
 // (3 stage buffers of 128 slots), D = 1 takes unions up to 192 (2 buffers of 192 slots).
 __device__ uint64_t *g_stamps = nullptr;
-template <int FIN, int FOUT, int NW, int D>
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY>
 __global__ __launch_bounds__(NW * 64) void k_wide(
     const int32_t *__restrict__ t_rows, const uint16_t *__restrict__ t_lid,
     const float *__restrict__ t_val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
     int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu) {
-  constexpr int KU = D == 2 ? 128 : kUCap;              // union slots staged per chunk
   constexpr int NSTG = D + 1;                           // stage buffers
   constexpr int kStageBytes = KU * kFC * 4;
   constexpr int NC = FIN / kFC;                         // chunks per tile
@@ -308,27 +311,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     return -1;
   };
 
-  auto mfma = [&](int ab, auto cc) {
-    constexpr int c = decltype(cc)::value;
-    const char *abase = lds + kOffA + ab * kABytes;
-#pragma unroll
-    for (int ti = 0; ti < NTT; ++ti) {
-      const char *ap = abase + (((tt0 + ti * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(ap + k2 * 64);
-        const bf16x8 alo = *reinterpret_cast<const bf16x8 *>(ap + k2 * 64 + kAImg);
-        const int ks = 2 * c + k2;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], alo, d[ct][ti], 0, 0, 0);
-          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ct][ks], ahi, d[ct][ti], 0, 0, 0);
-          d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], ahi, d[ct][ti], 0, 0, 0);
-        }
-      }
-    }
-  };
-
   // ---- prologue: chunks 0 .. D in flight, aggregate(0) -------------------------------------------------
   // chunk s = (tile s / NC, chunk s % NC) lives in stage[s % NSTG], its aggregate in A[s % 2], its tile's
   // entries in ent[(s / NC) % 3]
@@ -382,15 +364,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       // ---- stores of tile i-1: a tile whose 64 rows all exist is stored region by region with every lane
       // active (exact instruction counts for the waits); the last tile of a member at once, guarded, drained
       bool spread_stores = false;
-      float *om = nullptr;
-      int row0 = 0;
+      float *obase = nullptr;                             // this lane's first output element of the tile
       if (c == 0 && i > 0) {
         int ms, ts;
         split_tile(tile_of(i - 1), ms, ts);
         if ((ts + 1) * kRows <= N) {
           spread_stores = true;
-          om = out + (int64_t)ms * mstride_o;
-          row0 = ts * kRows;
+          obase = out + (int64_t)ms * mstride_o + (int64_t)(ts * kRows + tt0 * 16 + mi) * ldo +
+                  (CT * jw * 16 + 4 * mh);
         } else {
           store_tile(tile_of(i - 1));                   // drains
         }
@@ -444,7 +425,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         // memory instructions of this region
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          if (q * NU / NQ != u) continue;
+          if ((EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
           int32_t r0 = r[4 * q], r1 = r[4 * q + 1], r2 = r[4 * q + 2], r3 = r[4 * q + 3];
           asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));      // in SGPRs: selects, no branches
           if (r0 >= 0) {
@@ -468,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           for (int ti = 0; ti < NTT; ++ti) {
             if ((ti == 0 ? 0 : 2 * ti - 1) != u) continue;
             if (spread_stores) {
-              const int rr = row0 + (tt0 + ti * TSTEP) * 16 + mi;
+              float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) {
                 const int j = CT * jw + ct;
@@ -478,14 +459,13 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
                   for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
                 }
-                *reinterpret_cast<float4_t *>(om + (int64_t)rr * ldo + j * 16 + 4 * mh) = o;
+                *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
                 d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
               }
               n_ops += CT;
             }
           }
         }
-        STAMP(3);
         // aggregate stages of this region: LDS reads, then the unit's MFMAs, then the VALU work
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k)
@@ -510,7 +490,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, WEAVE_VALU, 0);     // a few VALU instructions behind it
         }
-        STAMP(4);
       });
       // what may stay in flight at the next wait: with two chunks of DMA in flight, everything this interval
       // issued (the DMA the next wait is for is older); with one, nothing (that DMA is among them)
@@ -524,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
 }
 
-template <int FIN, int FOUT, int NW, int D>
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY>
 int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st) {
@@ -538,7 +517,7 @@ int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, con
   const int64_t T = (N + kRows - 1) / kRows, G = T * members;
   if (G >= (int64_t(1) << 31)) return GWEN_ERANGE;
   const int64_t blocks = G < cus ? G : cus;
-  k_wide<FIN, FOUT, NW, D><<<(unsigned)blocks, NW * 64, 0, st>>>(t_rows, t_lid, t_val, x, W, bias, out,
+  k_wide<FIN, FOUT, NW, D, KU, EARLY><<<(unsigned)blocks, NW * 64, 0, st>>>(t_rows, t_lid, t_val, x, W, bias, out,
                                                                 (int32_t)N, (int32_t)T, (int32_t)G, ldo,
                                                                 msx, mso, relu);
   GWEN_LAUNCH_CHECK();
@@ -581,12 +560,20 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
   hipStream_t st = gwen_stream(stream_);
   // unions of at most 128 rows leave room for a third stage buffer: two chunks of DMA in flight.
   // 16 waves where the registers allow (Fin <= 128), 8 at Fin = 256 (W alone is 128 registers there).
-  const bool deep = union_max <= 128;
+  const bool small_union = union_max <= 128;
+  static const int mode = getenv("GWEN_WIDE_MODE") ? atoi(getenv("GWEN_WIDE_MODE")) : 0;
 #define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
 #define GWEN_W(FI, FO)                                                                                \
-  if (Fin == FI && Fout == FO)                                                                        \
-    return deep ? launch<FI, FO, (FI >= 256 ? 8 : 16), 2>(GWEN_ARGS)                                  \
-                : launch<FI, FO, (FI >= 256 ? 8 : 16), 1>(GWEN_ARGS)
+  if (Fin == FI && Fout == FO) {                                                                      \
+    constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
+    if (!small_union) return launch<FI, FO, NWV, 1, 192, false>(GWEN_ARGS);                           \
+    switch (mode) {                                                                                   \
+      case 1: return launch<FI, FO, NWV, 1, 128, false>(GWEN_ARGS);                                   \
+      case 2: return launch<FI, FO, NWV, 1, 128, true>(GWEN_ARGS);                                    \
+      case 3: return launch<FI, FO, NWV, 2, 128, true>(GWEN_ARGS);                                    \
+      default: return launch<FI, FO, NWV, 2, 128, false>(GWEN_ARGS);                                  \
+    }                                                                                                 \
+  }
   GWEN_W(64, 64); GWEN_W(64, 128); GWEN_W(64, 256);
   GWEN_W(128, 64); GWEN_W(128, 128); GWEN_W(128, 256);
   GWEN_W(256, 64); GWEN_W(256, 128); GWEN_W(256, 256);

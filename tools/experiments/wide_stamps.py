@@ -23,7 +23,7 @@ for _ in range(3):
     assert rc == 0
 torch.cuda.synchronize()
 t = st.view(256, NW, 6).double().cpu()
-names = ["loop + row-id loads", "vmcnt wait", "barrier", "memory instrs of regions", "compute of regions", "-"]
+names = ["everything between barrier and the next wait", "vmcnt wait", "barrier", "-", "-", "-"]
 tot = t.sum(-1)
 print(f"nu={nu} F={F} M={M}: per-wave stamped ticks (100 MHz s_memtime = 10 ns?) mean total {tot.mean():.0f}, min {tot.min():.0f}, max {tot.max():.0f}")
 for k, nm in enumerate(names):
