@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--nu", type=int, default=100)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--graph", default="mesh", choices=["mesh", "g2m", "m2g"])
-    ap.add_argument("--reorder", default="morton", choices=["none", "morton"])
+    ap.add_argument("--reorder", default="morton", choices=["none", "morton", "hilbert"])
     ap.add_argument("--act", default="silu", choices=["none", "relu", "silu"])
     args = ap.parse_args()
     dev = "cuda:0"
