@@ -73,7 +73,6 @@ extern "C" int gwen_gnn_backward_f32(const gwen_graph *graph_t, const gwen_layer
   if (!scratch || scratch_floats < P.total) return GWEN_ENOSPACE;
   if (!gwen_aligned(scratch, 16)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
-  hipStream_t st = gwen_stream(stream);
   const int64_t rows = members * N;
   float *gbuf[2] = {scratch + P.g0, scratch + P.g1};
   float *gh = scratch + P.gh;
