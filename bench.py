@@ -25,6 +25,8 @@ Extra objects on the JSON line (DESIGN.md "Measurement"):
                    per-GPU load of config c5 -- 410 MB per activation buffer, far beyond the Infinity Cache.
                    Its roofline: compulsory bytes (every input, output, index and weight byte once) / mean
                    kernel duration / 8 TB/s; traffic = PMC bytes from the committed rocprofv3 passes.
+  hbm_leg_64ch  -- the same stack at c2's 64 channels on 16 members (819 MB of activations per layer): the layer
+                   kernel where the 3xbf16 matrix work is a quarter of the 256-channel one per byte.
   exact_f32     -- the c2 step with every contraction on the fp32-input MFMA (order "fused_exact").
   cpu_baseline  -- the torch oracle (kind "port": the reference's PyG is not installable) timed on this
                    host's cores, all cores and one thread, rank 0, N = 1 only.
@@ -79,6 +81,7 @@ def parse():
     p.add_argument("--no-exact", action="store_true")
     p.add_argument("--hbm-members", type=int, default=4)
     p.add_argument("--hbm-channels", type=int, default=256)
+    p.add_argument("--hbm-members-narrow", type=int, default=16, help="members of the 64-channel HBM leg")
     p.add_argument("--hbm-layers", type=int, default=4)
     p.add_argument("--hbm-steps", type=int, default=12)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU baseline leg")
@@ -191,10 +194,10 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30):
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
-def hbm_leg(ga, mesh, graph, args, dev):
+def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's per-GPU load"):
     """BASELINE c3's processor stack at c5's per-GPU member count: the regime where HBM bounds the path."""
     n, e = mesh.num_nodes, mesh.num_edges
-    f, m, nl = args.hbm_channels, args.hbm_members, args.hbm_layers
+    f, m, nl = f or args.hbm_channels, m or args.hbm_members, args.hbm_layers
     torch.manual_seed(23)
     layers = []
     for _ in range(nl):
@@ -227,7 +230,7 @@ def hbm_leg(ga, mesh, graph, args, dev):
     # one member against the CPU oracle's first layer would take minutes at this width; parity at this size
     # is tests/test_gpu_wide.py::test_c3_layer_at_config_size_four_members
     return {
-        "workload": f"c3 stack at c5's per-GPU load: {nl} chained GCN layers {f}->{f} + ReLU, {m} members, "
+        "workload": f"{what}: {nl} chained GCN layers {f}->{f} + ReLU, {m} members, "
                     f"nu={args.nu} N={n} E={e}; {ws_mib:.0f} MiB in+out per layer (Infinity Cache: 256 MiB)",
         "members": m, "channels": f, "layers": nl, "steps": steps,
         "ms_per_step": round(dt * 1e3, 4),
@@ -449,6 +452,9 @@ def main():
     # ---- HBM-bound leg ----------------------------------------------------------------------------------
     if single and not args.no_hbm_leg:
         line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev)
+        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache
+        line["hbm_leg_64ch"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
+                                       what="c2's width beyond the Infinity Cache")
 
     # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline

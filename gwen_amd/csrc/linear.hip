@@ -264,6 +264,10 @@ inline int splitk_factor(int64_t rows, int64_t Fin, int64_t Fout) {
 
 }  // namespace
 
+// wide.hip: the K8 pipeline without a graph (tall inputs, Fin and Fout in {64, 128, 256})
+int gwen_wide_dense_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows, int64_t Fin,
+                        int64_t Fout, int64_t ldx, int64_t ldh, int relu, hipStream_t st);
+
 extern "C" int64_t gwen_gcn_linear_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout) {
   if (rows <= 0 || Fin <= 0 || Fout <= 0) return 0;
   const int n = splitk_factor(rows, Fin, Fout);
@@ -280,6 +284,23 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
   if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
   const bool vec = Fin % 4 == 0 && ldx % 4 == 0 && gwen_aligned(x, 16) && gwen_aligned(W, 16);
+  // Tall inputs at the widths K8 is built for run on its pipeline (rows DMA-staged through LDS, W resident in
+  // registers, persistent blocks): output columns in groups of 256 / 128 / 64, each group one pass over x.
+  // (measured, tools/experiments/k3_time.py: 256 -> 256 on 100 002 rows 76 -> 58 us, on 400 008 rows 338 -> 231 us;
+  // equal from ~16 000 rows down, where the 128 x 128 tiles of k_linear_split fill the chip as well)
+  const bool tall = rows >= 16384;
+  if (!exact && tall && vec && (Fin == 64 || Fin == 128 || Fin == 256) && Fout % 64 == 0 && Fout <= 2048 &&
+      ldh % 4 == 0 && gwen_aligned(h, 16) && (!bias || gwen_aligned(bias, 16)) &&
+      rows * ldx * 4 < (int64_t(1) << 32) && x != h) {
+    for (int64_t c0 = 0; c0 < Fout;) {
+      const int64_t left = Fout - c0, g = left >= 256 ? 256 : left >= 128 ? 128 : 64;
+      const int rc = gwen_wide_dense_f32(x, W + c0 * Fin, bias ? bias + c0 : nullptr, h + c0, rows, Fin, g, ldx,
+                                         ldh, relu, st);
+      if (rc != GWEN_OK) return rc;
+      c0 += g;
+    }
+    return GWEN_OK;
+  }
   if (!exact && Fin > 0) {      // Fin == 0: nothing to contract, the exact kernel writes act(bias)
     const int bn = Fout <= 64 ? 64 : SBN;           // narrow outputs: 64-column blocks, no empty tiles
     const int64_t sx = (rows + SBM - 1) / SBM, sy = (Fout + bn - 1) / bn;

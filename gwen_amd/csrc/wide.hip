@@ -108,12 +108,15 @@ __device__ inline void wait_vmcnt(int n) {
 
 // D = chunks of DMA in flight behind the one being aggregated: D = 2 needs unions of at most 128 rows
 // (3 stage buffers of 128 slots), D = 1 takes unions up to 192 (2 buffers of 192 slots).
-template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY>
+// DENSE: no graph -- the "union" of a tile is its own 64 rows and the aggregate is the row itself: the kernel is
+// then K3's 3xbf16 projection out = act(x W^T + b) for tall inputs (gwen_gcn_linear_f32 sends them here), with
+// x rows at pitch ldx.
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE>
 __global__ __launch_bounds__(NW * 64) void k_wide(
     const int32_t *__restrict__ t_rows, const uint16_t *__restrict__ t_lid,
     const float *__restrict__ t_val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
-    int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu) {
+    int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu, int32_t ldx) {
   constexpr int NSTG = D + 1;                           // stage buffers
   constexpr int kStageBytes = KU * kFC * 4;
   constexpr int NC = FIN / kFC;                         // chunks per tile
@@ -127,6 +130,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   static_assert(NC >= 1 && 4 % TSTEP == 0 && (NJ % NW == 0 || NW % NJ == 0), "unsupported widths");
   static_assert(NQ * 4 * NW == KU && NP * 4 * NW == kRows, "waves must tile the union and the rows");
   static_assert(NSTG * kStageBytes <= kStageAll, "stage buffers exceed their LDS region");
+  static_assert(!DENSE || KU == kRows, "a dense tile stages its own rows");
+  const uint32_t row_pitch = DENSE ? (uint32_t)ldx * 4u : (uint32_t)(FIN * 4);
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -194,6 +199,18 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     split_tile(g, m, t);
     const int32_t *rp = t_rows + (int64_t)t * kUCap + 4 * wave;   // wave-uniform: scalar loads
     const char *xm = uniform_ptr(x + (int64_t)m * mstride_x);
+    int n = 0;
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        int32_t row = t * kRows + 4 * (NW * q + wave) + mh;
+        row = row < N ? row : N - 1;                             // rows past the end: read a valid row, never stored
+        const uint32_t voff = (uint32_t)row * row_pitch + (uint32_t)(c * kFC * 4 + mi * 16);
+        glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
+        ++n;
+      }
+      return n;
+    }
     int32_t r[4 * NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -203,7 +220,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       asm volatile("" : "+s"(r[4 * q]), "+s"(r[4 * q + 1]), "+s"(r[4 * q + 2]), "+s"(r[4 * q + 3]));
-    int n = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       if (r[4 * q] >= 0) {
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         ++n;
       }
     }
-    if (c == 0 && wave < 3) {
+    if (!DENSE && c == 0 && wave < 3) {
       const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t * (kRows * 32) + wave * 1024
                                  : reinterpret_cast<const char *>(t_lid) + (int64_t)t * (kRows * 16);
       src = uniform_ptr(src);
@@ -229,6 +245,19 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   auto aggregate = [&](int sb, int ab, int eb) {
     const char *ent = lds + kOffEnt + eb * kEntBytes;
     const char *stg = lds + kOffStage + sb * kStageBytes + mi * 16;
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int lr = 4 * NW * p + 4 * wave + mh;
+        const float4_t a4 = *reinterpret_cast<const float4_t *>(stg + lr * (kFC * 4));
+        bf16x4 h4, l4;
+        split4(a4, h4, l4);
+        char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
+        *reinterpret_cast<bf16x4 *>(a) = h4;
+        *reinterpret_cast<bf16x4 *>(a + kAImg) = l4;
+      }
+      return;
+    }
     u32x4 lid4[NP];
     float4_t wgt[NP][2];
 #pragma unroll
@@ -334,6 +363,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   int sb = 0;                 // s % NSTG
   int eb = 0;                 // i % 3
   int young = 0;              // operations that may stay in flight at the next wait
+  int prev_ops = 0;           // what the interval before this one issued (D = 3)
   for (int i = 0; i < ntl; ++i) {
     gwen_static_for<NC>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
@@ -346,10 +376,12 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       const int32_t *rp = t_rows + (int64_t)t2 * kUCap + 4 * wave;          // wave-uniform: scalar loads
       const char *xm = uniform_ptr(x + (int64_t)m2 * mstride_x);
       int32_t r[4 * NQ];
+      if constexpr (!DENSE) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
+          for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
+      }
       wait_vmcnt(young);
       __syncthreads();
       int n_ops = 0;
@@ -380,7 +412,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       auto stage_loads = [&](int k) {                   // k = 4 pass + stage
         const int p = k >> 2, j = k & 3;
         const int lr = 4 * NW * p + 4 * wave + mh;
-        if (j == 0) {
+        if constexpr (DENSE) {
+          if (j == 1) v[0] = *reinterpret_cast<const float4_t *>(stg + lr * (kFC * 4));
+        } else if (j == 0) {
           lid4 = *reinterpret_cast<const u32x4 *>(ent + kRows * 32 + lr * 16);
           wa = *reinterpret_cast<const float4_t *>(ent + lr * 32);
           wb = *reinterpret_cast<const float4_t *>(ent + lr * 32 + 16);
@@ -396,7 +430,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       auto stage_valu = [&](int k) {
         const int p = k >> 2, j = k & 3;
         const int lr = 4 * NW * p + 4 * wave + mh;
-        if (j == 1 || j == 2) {
+        if constexpr (DENSE) {
+          if (j == 1) acc = v[0];
+        }
+        if (!DENSE && (j == 1 || j == 2)) {
           const float4_t w4 = j == 1 ? wa : wb;
           if (j == 1) acc = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -424,6 +461,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           if ((EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
+          if constexpr (DENSE) {
+            int32_t row = t2 * kRows + 4 * (NW * q + wave) + mh;
+            row = row < N ? row : N - 1;
+            const uint32_t voff = (uint32_t)row * row_pitch + (uint32_t)(c2 * kFC * 4 + mi * 16);
+            glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
+            ++n_ops;
+            continue;
+          }
           int32_t r0 = r[4 * q], r1 = r[4 * q + 1], r2 = r[4 * q + 2], r3 = r[4 * q + 3];
           asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));      // in SGPRs: selects, no branches
           if (r0 >= 0) {
@@ -436,7 +481,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             ++n_ops;
           }
         }
-        if (u == NU - 1 && c2 == 0 && wave < 3) {
+        if (!DENSE && u == NU - 1 && c2 == 0 && wave < 3) {
           const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t2 * (kRows * 32) + wave * 1024
                                      : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
@@ -497,7 +542,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       });
       // what may stay in flight at the next wait: with two chunks of DMA in flight, everything this interval
       // issued (the DMA the next wait is for is older); with one, nothing (that DMA is among them)
-      young = D == 2 ? n_ops : 0;
+      young = D == 3 ? n_ops + prev_ops : D == 2 ? n_ops : 0;
+      prev_ops = n_ops;
       sb = sb + 1 == NSTG ? 0 : sb + 1;
     });
     eb = eb + 1 == 3 ? 0 : eb + 1;
@@ -506,10 +552,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
 }
 
-template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY>
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false>
 int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
-           int64_t msx, int64_t mso, int relu, hipStream_t st) {
+           int64_t msx, int64_t mso, int relu, hipStream_t st, int64_t ldx = FIN) {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -520,9 +566,8 @@ int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, con
   const int64_t T = (N + kRows - 1) / kRows, G = T * members;
   if (G >= (int64_t(1) << 31)) return GWEN_ERANGE;
   const int64_t blocks = G < cus ? G : cus;
-  k_wide<FIN, FOUT, NW, D, KU, EARLY><<<(unsigned)blocks, NW * 64, 0, st>>>(t_rows, t_lid, t_val, x, W, bias, out,
-                                                                (int32_t)N, (int32_t)T, (int32_t)G, ldo,
-                                                                msx, mso, relu);
+  k_wide<FIN, FOUT, NW, D, KU, EARLY, DENSE><<<(unsigned)blocks, NW * 64, 0, st>>>(
+      t_rows, t_lid, t_val, x, W, bias, out, (int32_t)N, (int32_t)T, (int32_t)G, ldo, msx, mso, relu, (int32_t)ldx);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -531,6 +576,25 @@ constexpr bool fin_ok(int64_t f) { return f == 64 || f == 128 || f == 256; }
 constexpr bool fout_ok(int64_t f) { return f == 64 || f == 128 || f == 256; }
 
 }  // namespace
+
+// K3's tall case on the K8 pipeline: h[rows, Fout] = act(x[rows, Fin (pitch ldx)] W^T + b).  Internal: called by
+// gwen_gcn_linear_f32 (linear.hip), which has validated the pointers.
+int gwen_wide_dense_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows, int64_t Fin,
+                        int64_t Fout, int64_t ldx, int64_t ldh, int relu, hipStream_t st) {
+  if (!fin_ok(Fin) || !fout_ok(Fout) || rows * ldx * 4 >= (int64_t(1) << 32) || rows >= (int64_t(1) << 31) - 64)
+    return GWEN_ERANGE;
+#define GWEN_D(FI, FO)                                                                                  \
+  if (Fin == FI && Fout == FO) {                                                                        \
+    constexpr int NWV = FI >= 256 ? 8 : 16;                                                             \
+    return launch<FI, FO, NWV, 2, 64, true, true>(nullptr, nullptr, nullptr, x, W, bias, h, rows, ldh,  \
+                                                  1, 0, 0, relu, st, ldx);                              \
+  }
+  GWEN_D(64, 64); GWEN_D(64, 128); GWEN_D(64, 256);
+  GWEN_D(128, 64); GWEN_D(128, 128); GWEN_D(128, 256);
+  GWEN_D(256, 64); GWEN_D(256, 128); GWEN_D(256, 256);
+#undef GWEN_D
+  return GWEN_ERANGE;
+}
 
 extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
   return fin_ok(Fin) && fout_ok(Fout) ? 1 : 0;

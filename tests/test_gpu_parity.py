@@ -178,6 +178,37 @@ def test_linear(ga, cref, rows, fin, fout):
     assert rel_err(got3, ref3) <= 2e-5
 
 
+@pytest.mark.parametrize("rows,fin,fout", [(16384, 256, 256), (20001, 64, 64), (40007, 128, 320), (100002, 256, 768),
+                                            (16390, 64, 192), (33000, 128, 64)])
+def test_linear_tall(ga, rows, fin, fout):
+    """From 16 384 rows up the 3xbf16 projection runs on the K8 pipeline without a graph (wide.hip DENSE: rows
+    DMA-staged through LDS, output columns in groups of 256 / 128 / 64).  Same split, same MFMA sequence as the
+    128 x 128-tile kernel short inputs take: bitwise equal to it, and fp32-class against fp64."""
+    from gwen_amd import ops, _lib
+    from gwen_amd.graph import _ptr, _stream
+    gen = torch.Generator().manual_seed(SEED + rows + fout)
+    x = torch.randn(rows, fin, generator=gen).to(DEV)
+    w, b = make_params(fin, fout)
+    w, b = w.to(DEV), b.to(DEV)
+    got = ops.linear(x, w, b, relu=True, exact=False)
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert rel_err(got.cpu(), ref.cpu()) <= 2e-5
+    for lo in (0, rows - 8000):                                   # 8 000 rows at a time: the short kernel
+        part = ops.linear(x[lo:lo + 8000].contiguous(), w, b, relu=True, exact=False)
+        assert torch.equal(part, got[lo:lo + 8000])
+    plain = ops.linear(x, w, None, relu=False, exact=False)
+    assert rel_err(plain.cpu(), (x.double() @ w.double().t()).cpu()) <= 2e-5
+    # rows at a pitch (the C ABI's ldx / ldh): the left fin columns of a wider tensor into the right of another
+    wide_x = torch.randn(rows, fin + 64, generator=gen).to(DEV)
+    wide_o = torch.full((rows, fout + 32), -7.0, device=DEV)
+    rc = _lib.lib().gwen_gcn_linear_f32(_ptr(wide_x), _ptr(w), _ptr(b), wide_o.data_ptr() + 32 * 4, rows, fin, fout,
+                                        fin + 64, fout + 32, 1, 0, None, 0, _stream(torch.device(DEV)))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(wide_o[:, 32:], ops.linear(wide_x[:, :fin].contiguous(), w, b, relu=True, exact=False))
+    assert bool((wide_o[:, :32] == -7.0).all())
+
+
 # ------------------------------------------------------------------------------------------------
 # one layer and the whole model against the torch oracle (the "reference PyTorch CPU path")
 # ------------------------------------------------------------------------------------------------
