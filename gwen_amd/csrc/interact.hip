@@ -14,9 +14,10 @@
 // Shape (wave64): a block = 8 waves that walk tiles of at most 64 rows persistently (one resident set
 //   of blocks; the tiles of one XCD are one contiguous eighth of them);
 //   a wave owns NC column tiles (16 NC output columns) of BOTH contractions and keeps its slices of W1
-//   and W2 in registers as 3xbf16 fragments (hi/lo, see layer.hip) -- at 256 channels they are streamed
-//   from pre-split images instead -- with W as the MFMA A operand, so a lane ends up with 4 consecutive
-//   columns of one row (16-B gathers, 16-B stores);
+//   and W2 in registers as 3xbf16 fragments (hi/lo, see layer.hip) with W as the MFMA A operand, so a lane
+//   ends up with 4 consecutive columns of one row (16-B gathers, 16-B stores).  At 256 channels the
+//   fragments (512 KB) exceed the register file: that width runs on the row-stationary kernel of
+//   interact_rows.hip instead (weights streamed through an LDS ring, activations in registers);
 //   phase 1  A rows, prefetched during the previous pass in the OUTPUT layout (the residual stays in
 //            registers) -> hi/lo bf16 LDS tile;
 //   phase 2  pre = MFMA + gathered addends + b1, activation -> hi/lo hidden tile (its own LDS image);
@@ -34,7 +35,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxRows = 64;              // most rows a pass takes (MCfg<F>::ROWS)
+constexpr int kMaxRows = 128;             // most rows a pass takes (MCfg<F>::ROWS; 128 at 256 channels)
 
 template <int F>
 struct MCfg {
@@ -44,18 +45,13 @@ struct MCfg {
   static constexpr int ROWS = 64;
   static constexpr int NT = ROWS / 16;
   // A wave owns NC column tiles.  With one tile every hi/lo operand pair read from LDS feeds three
-  // MFMAs, with two it feeds six: at 256 channels (16 column tiles, weights streamed anyway) two
-  // tiles per wave measured 10 % faster; at 64 the doubled fragments and tiles spill, at 128 it is a wash.
-  static constexpr int NC = F == 256 ? 2 : 1;
+  // MFMAs, with two it would feed six: at 64 channels the doubled fragments and tiles spill, at 128 it is a wash.
+  static constexpr int NC = 1;
   static constexpr int NJW = NJ / NC;                            // column groups
   // every column group is shared by TSTEP waves (each takes every TSTEP-th 16-row tile)
   static constexpr int TSTEP = F == 32 ? 4 : (F == 64 ? 2 : 1);
   static constexpr int NWB = NJW * TSTEP;                        // waves per block: 8 at every width
   static constexpr int MINW = F >= 128 ? 2 : 4;                  // waves per SIMD to compile for
-  // F = 256: the two weight matrices as hi/lo fragments are 512 KB -- the whole register file of a
-  // CU -- so they cannot stay resident: they are pre-split once per launch into fragment-ordered bf16
-  // images (k_split_w) and every wave streams its slices from L2, one k-step ahead of the MFMAs
-  static constexpr bool STREAM = F > 128;
   static constexpr int TPW = NT / TSTEP;                         // row tiles per wave
   static constexpr int KS = F / 32;                              // k-steps of v_mfma_f32_16x16x32_bf16
   static constexpr int PB = ((F / 2) % 16 == 8 ? F / 2 : F / 2 + 8) * 2;   // hi/lo tile pitch (bf16)
@@ -156,60 +152,6 @@ __device__ inline void tiles_mma(const __bf16 *thi, const __bf16 *tlo, int tt0, 
   }
 }
 
-// weights streamed: img = fragment-ordered image of k_split_w (hi at 0, lo at F*F bf16), fragment
-// (jt, ks) of lane l at ((jt KS + ks) 64 + l) x 16 bytes -- one contiguous KB per wave load.
-template <int F>
-__device__ inline void tiles_mma_stream(const __bf16 *thi, const __bf16 *tlo, int tt0, int mi, int mh,
-                                        const bf16x8 *__restrict__ img, int jw, int lane,
-                                        f32x4 (&d)[MCfg<F>::TPW][MCfg<F>::NC]) {
-  using C = MCfg<F>;
-  const bf16x8 *ghi = img + (jw * C::NC * C::KS) * 64 + lane;
-  const bf16x8 *glo = ghi + F * F / 8;
-#pragma unroll
-  for (int k = 0; k < C::TPW; ++k)
-#pragma unroll
-    for (int n = 0; n < C::NC; ++n) d[k][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 wh[C::NC], wl[C::NC];
-#pragma unroll
-  for (int n = 0; n < C::NC; ++n) {
-    wh[n] = ghi[n * C::KS * 64];
-    wl[n] = glo[n * C::KS * 64];
-  }
-  // a rolled loop: unrolled, hipcc hoists every fragment load of the contraction and spills
-#pragma unroll 1
-  for (int ks = 0; ks < C::KS; ++ks) {
-    const int kn = ks + 1 < C::KS ? ks + 1 : ks;           // unconditional load, one k-step ahead
-    bf16x8 nh[C::NC], nl[C::NC];
-#pragma unroll
-    for (int n = 0; n < C::NC; ++n) {
-      nh[n] = ghi[(n * C::KS + kn) * 64];
-      nl[n] = glo[(n * C::KS + kn) * 64];
-    }
-    bf16x8 ahi[C::TPW], alo[C::TPW];
-    read_tiles<F>(thi, tlo, tt0, mi, mh, ks, ahi, alo);
-    mma_step<F>(ahi, alo, wh, wl, d);
-#pragma unroll
-    for (int n = 0; n < C::NC; ++n) {
-      wh[n] = nh[n];
-      wl[n] = nl[n];
-    }
-  }
-}
-
-// W [F,F] fp32 -> hi / lo bf16 images in fragment order (see tiles_mma_stream); one wave per (j, ks)
-template <int F>
-__global__ __launch_bounds__(64) void k_split_w(const float *__restrict__ W, bf16x8 *__restrict__ img) {
-  constexpr int KS = F / 32;
-  const int lane = threadIdx.x, mi = lane & 15, mh = lane >> 4;
-  const int j = blockIdx.x / KS, ks = blockIdx.x % KS;
-  const float *wp = W + (int64_t)(j * 16 + mi) * F + 8 * (4 * ks + mh);
-  bf16x4 h0, l0, h1, l1;
-  split4(*reinterpret_cast<const float4_t *>(wp), h0, l0);
-  split4(*reinterpret_cast<const float4_t *>(wp + 4), h1, l1);
-  img[blockIdx.x * 64 + lane] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-  img[F * F / 8 + blockIdx.x * 64 + lane] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-}
-
 // SiLU on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each): x / (1 + 2^(-x log2 e))
 __device__ inline float4_t activate(float4_t v, int act) {
   if (act == GWEN_ACT_RELU) {
@@ -254,15 +196,12 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
   // this lane's output columns: 4 consecutive ones in each of the wave's NC column tiles
   auto col = [&](int n) { return (jw * C::NC + n) * 16 + 4 * mh; };
 
-  // resident: this wave's hi/lo fragments of both matrices; streamed: W1 / W2 point at the images
-  constexpr int KR = C::STREAM ? 1 : C::KS;
-  bf16x8 w1hi[C::NC][KR], w1lo[C::NC][KR], w2hi[C::NC][KR], w2lo[C::NC][KR];
-  if constexpr (!C::STREAM) {
+  // resident: this wave's hi/lo fragments of both matrices
+  bf16x8 w1hi[C::NC][C::KS], w1lo[C::NC][C::KS], w2hi[C::NC][C::KS], w2lo[C::NC][C::KS];
 #pragma unroll
-    for (int n = 0; n < C::NC; ++n) {
-      load_w<F>(W1, jw * C::NC + n, mi, mh, w1hi[n], w1lo[n]);
-      load_w<F>(W2, jw * C::NC + n, mi, mh, w2hi[n], w2lo[n]);
-    }
+  for (int n = 0; n < C::NC; ++n) {
+    load_w<F>(W1, jw * C::NC + n, mi, mh, w1hi[n], w1lo[n]);
+    load_w<F>(W2, jw * C::NC + n, mi, mh, w2hi[n], w2lo[n]);
   }
   float4_t b1v[C::NC], b2v[C::NC];
 #pragma unroll
@@ -326,9 +265,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     span(tn, nxt);
   }
   prefetch(cur);
-  // The gathered addends of a pass: requested at its top (the indices came with its prefetch).  At 256
-  // channels they are requested a pass EARLY instead -- right after the previous pass's second
-  // contraction -- which measured -9 % there (970 -> 885 us) and +4..6 % at 64 / 128 channels.
+  // The gathered addends of a pass: requested at its top (the indices came with its prefetch).
   float4_t add[C::TPW][C::NC];
   auto gather_addends = [&]() {
 #pragma unroll
@@ -344,11 +281,10 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
               reinterpret_cast<const char *>(G2) + ((uint32_t)i2[k] * ldb2 + col(n) * 4u));
       }
   };
-  if constexpr (C::STREAM) gather_addends();               // first pass: no earlier point exists
   for (;;) {
     const int32_t n_rows = cur.e1 - cur.w0;                // valid rows of this pass (<= 0: none)
     // ---- the gathered addends of this lane's rows (indices came with the prefetch) ---------------
-    if constexpr (!C::STREAM) gather_addends();
+    gather_addends();
     // phase 4's row bounds for this thread's first target row, requested early
     int32_t seg_s = 0, seg_e = 0;
     if constexpr (SEG) {
@@ -388,10 +324,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     // (the hidden tile has its own LDS image: the previous pass's second contraction, which read it,
     //  lies before the barrier above for every wave)
     f32x4 d[C::TPW][C::NC];
-    if constexpr (C::STREAM)
-      tiles_mma_stream<F>(thi, tlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W1), jw, lane, d);
-    else
-      tiles_mma<F>(thi, tlo, tt0, mi, mh, w1hi, w1lo, d);
+    tiles_mma<F>(thi, tlo, tt0, mi, mh, w1hi, w1lo, d);
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
@@ -421,11 +354,7 @@ __global__ __launch_bounds__(MCfg<F>::NWB * 64, MCfg<F>::MINW) void k_mlp2(
     __syncthreads();
     // ---- phase 3: second contraction, residual, store ---------------------------------------------
     float4_t y[C::TPW][C::NC];
-    if constexpr (C::STREAM)
-      tiles_mma_stream<F>(hhi, hlo, tt0, mi, mh, reinterpret_cast<const bf16x8 *>(W2), jw, lane, d);
-    else
-      tiles_mma<F>(hhi, hlo, tt0, mi, mh, w2hi, w2lo, d);
-    if constexpr (C::STREAM) gather_addends();             // for the NEXT pass (i1 / i2 hold its indices)
+    tiles_mma<F>(hhi, hlo, tt0, mi, mh, w2hi, w2lo, d);
 #pragma unroll
     for (int k = 0; k < C::TPW; ++k) {
       const int row = (tt0 + k * C::TSTEP) * 16 + mi;
@@ -514,14 +443,7 @@ int launch(const float *A, const float *W1, const float *G1, const int32_t *idx1
            hipStream_t st) {
   using C = MCfg<F>;
   const bool seg = agg != nullptr;
-  if constexpr (C::STREAM) {           // pre-split both matrices into fragment-ordered bf16 images
-    bf16x8 *img1 = reinterpret_cast<bf16x8 *>(workspace), *img2 = img1 + 2 * F * F / 8;
-    k_split_w<F><<<C::NJ * C::KS, 64, 0, st>>>(W1, img1);
-    k_split_w<F><<<C::NJ * C::KS, 64, 0, st>>>(W2, img2);
-    GWEN_LAUNCH_CHECK();
-    W1 = reinterpret_cast<const float *>(img1);
-    W2 = reinterpret_cast<const float *>(img2);
-  }
+  (void)workspace;
   const int64_t tiles = seg ? n_tiles : (R + C::ROWS - 1) / C::ROWS;
   // W1 and W2 (2 x 16 F^2 bytes per block) are fetched once per block: one resident set of blocks
   // walks the tiles, each prefetching its next pass while it computes the current one
@@ -563,13 +485,21 @@ int launch_mode(int m1, int m2, const float *A, const float *W1, const float *G1
 
 }  // namespace
 
+// interact_rows.hip: the row-stationary kernel 256 channels run on
+int gwen_mlp2_rows_f();
+int gwen_mlp2_rows_launch(int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,
+                          const float *G2, const int32_t *idx2, const float *b1, const float *W2,
+                          const float *b2, const float *res, float *out, int64_t R, int act,
+                          const int32_t *rowptr, const int32_t *tile_row, int64_t n_tiles, float *agg,
+                          int mean, void *workspace, uint32_t ldb1, uint32_t ldb2, hipStream_t st);
+
 extern "C" int gwen_mlp2_supported(int64_t F) {
   return F == 32 || F == 64 || F == 128 || F == 256 ? 1 : 0;
 }
 
 extern "C" int gwen_mlp2_rows(int64_t F) {
   return F == 32 ? MCfg<32>::ROWS : F == 64 ? MCfg<64>::ROWS : F == 128 ? MCfg<128>::ROWS
-       : F == 256 ? MCfg<256>::ROWS : GWEN_EINVAL;
+       : F == 256 ? gwen_mlp2_rows_f() : GWEN_EINVAL;
 }
 
 extern "C" int64_t gwen_mlp2_workspace_bytes(int64_t F) {
@@ -633,7 +563,10 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
     return launch_mode<FF>(m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, \
                            tile_row, n_tiles, agg, mean, workspace, (uint32_t)(ldg1 * 4),       \
                            (uint32_t)(ldg2 * 4), st)
-  GWEN_M(32); GWEN_M(64); GWEN_M(128); GWEN_M(256);
+  GWEN_M(32); GWEN_M(64); GWEN_M(128);
 #undef GWEN_M
+  if (F == 256)
+    return gwen_mlp2_rows_launch(m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, tile_row,
+                                 n_tiles, agg, mean, workspace, (uint32_t)(ldg1 * 4), (uint32_t)(ldg2 * 4), st);
   return GWEN_EINVAL;
 }

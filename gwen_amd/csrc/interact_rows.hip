@@ -1,0 +1,492 @@
+// K6 at 256 channels, ROW-STATIONARY -- the same contract as k_mlp2 (interact.hip):
+//
+//     pre[r] = A[r] W1^T + G1[idx1[r]] + G2[idx2[r]] + b1 ;  y[r] = act(pre[r]) W2^T + b2
+//     out[r] = res[r] + y[r] ;  agg[d] = sum_{r : dst(r) = d} y[r]      (rows sorted by d, stored order)
+//
+// At 256 channels the two weight matrices as 3xbf16 hi/lo fragments are 512 KB, the whole register file of a
+// CU, so they cannot stay resident.  k_mlp2 keeps the activations in LDS and lets every wave stream ITS
+// column slice of W from L2, one k-step ahead: per 64-row pass a CU pulls 512 KB of fragments through the
+// vector memory path, each k-step (384 cycles of MFMA per wave) waits for an L2 round trip, and the hidden
+// layer crosses LDS between two barriers (measured: 890 us for 600 000 edges = 0.21 of the bf16 MFMA peak;
+// 690 us with the fragment loads removed).  Here the roles are swapped:
+//   * a wave owns 16 ROWS and all 256 columns of them -- its A rows, the first contraction's accumulators
+//     (= the hidden layer) and the second one's live in registers, three sets of 64; a lane holds, of row
+//     lane % 16, the 4 columns 16 j + 4 (lane / 16) .. + 3 of every 16-column tile j;
+//   * the k index of a contraction may be permuted freely as long as both operands agree, so a k-step takes
+//     as "its" 32 channels the two column tiles 2 ks and 2 ks + 1 in exactly that register layout: the B
+//     operand (8 values per lane) is read straight from the lane's registers -- the A rows for the first
+//     contraction, the activated accumulators for the second -- and the hidden layer never touches LDS;
+//     the weight images (k_split_wr) are written in the matching order;
+//   * the weights are the shared operand: one k-step of a matrix is 32 KB of fragments for ALL 16 column
+//     tiles, brought by LDS-DMA (global_load_lds_dwordx4, no registers) into a ring of three slots, two
+//     k-steps ahead, and read by all 8 waves -- 256 KB per 128-row pass and matrix instead of 512 KB per 64;
+//   * one barrier per k-step (it frees the slot the next DMA overwrites); the aggregation goes through a
+//     64-column fp32 tile in LDS four times per pass, summed per target row in stored order by one thread
+//     per (row, 4 columns) as in k_mlp2 -- no atomics, bitwise reproducible.
+// The DMAs are inline asm (hipcc neither counts nor drains them); the waits for them are explicit and count
+// the vector-memory instructions issued since (cdna_hip_programming.md, "Pipelining across barriers").
+// Register roles rotate: the next pass's A rows are loaded into the hidden layer's registers as the second
+// contraction releases them, and the finished pass's A registers receive the next pass's gathered G2 rows
+// (the first contraction accumulates onto them), so the pass body exists twice with the two sets swapped.
+#include "common.h"
+#include <type_traits>
+#ifndef ABL
+#define ABL 0
+#endif
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kNone = 0, kSelf = 1, kIdx = 2;      // how a table is addressed (as interact.hip)
+constexpr int kResNone = 0, kResA = 1, kResOther = 2;
+
+template <int F>
+struct RCfg {
+  static constexpr int NJ = F / 16;                 // column tiles = float4 registers per row and set
+  static constexpr int KS = F / 32;                 // k-steps per contraction
+  static constexpr int NW = 8;                      // waves per block
+  static constexpr int ROWS = NW * 16;              // rows per pass
+  static constexpr int STEP = NJ * 2 * 1024;        // bytes of W fragments per k-step: (tile, hi/lo) x 1 KB
+  static constexpr int NSLOT = 3;
+  static constexpr int DPW = STEP / 1024 / NW;      // DMA instructions per wave and k-step
+  static constexpr int YC = 64, PY = YC + 4;        // aggregation chunk: columns, LDS pitch (floats)
+  static constexpr int NCH = F / YC, JC = YC / 16;
+  static constexpr int kOffY = NSLOT * STEP;
+  static constexpr int kOffB = kOffY + ROWS * PY * 4;
+  static constexpr int lds_bytes = kOffB + 2 * F * 4;
+  static constexpr int Q = YC / 4;                  // 16-B pieces per chunk row
+  static constexpr int SLOTS = NW * 64 / Q;         // target rows reduced at a time
+  static_assert(STEP % (1024 * NW) == 0 && lds_bytes <= 160 * 1024, "ring must tile over the waves and fit");
+};
+
+template <int N, typename Fn, int I = 0>
+__device__ inline void static_for(Fn &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, Fn, I + 1>(static_cast<Fn &&>(f));
+  }
+}
+
+__device__ inline const char *uniform_ptr(const void *p) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
+}
+
+// one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) to LDS byte address dst + 16 l
+__device__ inline void glds16(const void *base, uint32_t voff, uint32_t dst) {
+  uint32_t keep;       // M0 is compiler-reserved: save and restore it inside the statement
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
+template <int N>
+__device__ inline void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ inline void split8(const float4_t a, const float4_t b, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __bf16 h = (__bf16)a[i];
+    hi[i] = h; lo[i] = (__bf16)(a[i] - (float)h);
+    h = (__bf16)b[i];
+    hi[i + 4] = h; lo[i + 4] = (__bf16)(b[i] - (float)h);
+  }
+}
+
+__device__ inline float4_t activate(float4_t v, int act) {
+  if (act == GWEN_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] < 0.0f ? 0.0f : v[i];
+  } else if (act == GWEN_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = v[i] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[i] * -1.44269504088896341f));
+  }
+  return v;
+}
+
+// W [F,F] fp32 (row = output column) -> the k-step-major fragment image: k-step ks, column tile jo, (hi, lo),
+// lane l = (i = l % 16, g = l / 16): the 8 values W[16 jo + i][32 ks + 4 g .. + 3], W[16 jo + i][32 ks + 16 + 4 g .. + 3]
+template <int F>
+__global__ __launch_bounds__(64) void k_split_wr(const float *__restrict__ W, bf16x8 *__restrict__ img) {
+  using C = RCfg<F>;
+  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int jo = blockIdx.x / C::KS, ks = blockIdx.x % C::KS;
+  const float *wp = W + (int64_t)(jo * 16 + i) * F + 32 * ks + 4 * g;
+  bf16x8 hi, lo;
+  split8(*reinterpret_cast<const float4_t *>(wp), *reinterpret_cast<const float4_t *>(wp + 16), hi, lo);
+  bf16x8 *dst = img + (int64_t)ks * (C::STEP / 16) + (jo * 2) * 64 + lane;
+  dst[0] = hi;
+  dst[64] = lo;
+}
+
+struct Pass {
+  int32_t tile, r0, r1;
+  int32_t w0, e0, e1;
+};
+
+// visible (hipcc-counted) vector-memory instructions step si of a pass issues after its DMAs: the first
+// contraction's steps load the G1 rows (4 tiles a step, steps 0-3) and, with a residual other than A, its rows;
+// the second one's load the next pass's A rows (2 tiles a step) and, in its first step, the next indices
+template <int F, int M1, int M2, int RES>
+struct Vis {
+  static constexpr int of(int si) {
+    using C = RCfg<F>;
+    if (si < C::KS) return ((M1 != kNone && si < 4) ? C::NJ / 4 : 0) + (RES == kResOther ? 2 : 0);
+    return 2 + (si == C::KS ? (M1 == kIdx ? 1 : 0) + (M2 == kIdx ? 1 : 0) : 0);
+  }
+};
+
+template <int F, int M1, int M2, bool SEG, int RES>
+__global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
+    const float *__restrict__ A, const char *__restrict__ img, const float *__restrict__ G1,
+    const int32_t *__restrict__ idx1, const float *__restrict__ G2, const int32_t *__restrict__ idx2,
+    const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ res,
+    float *__restrict__ out, int32_t R, int act, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ tile_row, int32_t n_tiles, float *__restrict__ agg, int mean,
+    uint32_t ldb1, uint32_t ldb2) {
+  using C = RCfg<F>;
+  __shared__ __attribute__((aligned(1024))) char lds[C::lds_bytes];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+  float *ytile = reinterpret_cast<float *>(lds + C::kOffY);
+  float *bl = reinterpret_cast<float *>(lds + C::kOffB);           // b1 | b2
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int mi = lane & 15, g = lane >> 4;
+  const int prow = wave * 16 + mi;                                   // this lane's row within a pass
+  auto col = [&](int j) { return 16 * j + 4 * g; };                  // its 4 columns of column tile j
+
+  for (int f = t; f < F; f += C::NW * 64) {
+    bl[f] = b1 ? b1[f] : 0.0f;
+    bl[F + f] = b2 ? b2[f] : 0.0f;
+  }
+
+  // tiles are dealt so that the blocks of one XCD (blockIdx % 8) walk ONE contiguous eighth of them
+  const int nb = gridDim.x, xcd = blockIdx.x & 7;
+  const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+  const int t_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int t_hi = t_lo + q8 + (xcd < r8 ? 1 : 0);
+  const int stride = (nb + 7 - xcd) >> 3;                            // blocks on this XCD
+  const int tile0 = t_lo + (blockIdx.x >> 3);
+  if (tile0 >= t_hi) return;
+
+  auto span = [&](int32_t tile, Pass &p) {                           // uniform: scalar loads
+    p.tile = tile;
+    if constexpr (SEG) {
+      p.r0 = tile_row[tile];
+      p.r1 = tile_row[tile + 1];
+      p.e0 = rowptr[p.r0];
+      p.e1 = rowptr[p.r1];
+    } else {
+      p.r0 = p.r1 = 0;
+      p.e0 = tile * C::ROWS;
+      p.e1 = p.e0 + C::ROWS < R ? p.e0 + C::ROWS : R;
+    }
+    p.w0 = p.e0;
+  };
+  // rows beyond the pass are clamped to its last row (always a valid row: R >= 1)
+  auto clamp_row = [&](const Pass &p) {
+    int32_t rr = p.w0 + prow;
+    const int32_t last = (p.e1 < R ? p.e1 : R) - 1;
+    rr = rr < last ? rr : last;
+    return rr < 0 ? 0 : rr;
+  };
+
+  // ---- the weight ring: chunk c (0 .. 2 KS - 1: W1's k-steps, then W2's) is the same for every pass ---------
+  const char *img_w = uniform_ptr(img + (int64_t)wave * C::DPW * 1024);
+  int slot = 0;                                                      // slot of the chunk the next step consumes
+  auto dma = [&](int chunk, int into) {                              // this wave's share of one chunk
+#pragma unroll
+    for (int q = 0; q < C::DPW; ++q)
+      glds16(img_w, (uint32_t)(chunk * C::STEP + q * 1024 + lane * 16),
+             __builtin_amdgcn_readfirstlane(lds0 + into * C::STEP + (wave * C::DPW + q) * 1024));
+  };
+
+  float4_t ra[C::NJ], rb[C::NJ], rc[C::NJ];
+  int32_t i1 = 0, i2 = 0;                                            // table rows of the CURRENT pass's row
+  int32_t i1n = 0, i2n = 0;                                          // ... of the next pass's
+
+  Pass cur, nxt;
+  span(tile0, cur);
+  {
+    const int32_t tn = tile0 + stride < t_hi ? tile0 + stride : tile0;
+    span(tn, nxt);
+  }
+  {                                                                  // first pass: rows, indices, G2 rows
+    const int32_t rr = clamp_row(cur);
+    i1 = M1 == kIdx ? idx1[rr] : rr;
+    i2 = M2 == kIdx ? idx2[rr] : rr;
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) {
+      ra[j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + col(j));
+      if constexpr (M2 != kNone)
+        rb[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G2) +
+                                                    ((uint32_t)i2 * ldb2 + col(j) * 4u));
+      else
+        rb[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  dma(0, 0);
+  dma(1, 1);
+
+  using V = Vis<F, M1, M2, RES>;
+
+  bool last_pass = false;
+  // One pass.  E: this pass's A rows (later the residual).  H: pre-loaded with the G2 rows (or zero) -- the first
+  // contraction accumulates onto it, the activation turns it into the hidden layer, the second contraction
+  // consumes it and the NEXT pass's A rows move in.  rc: G1 rows, then the second contraction's accumulators.
+  auto pass_body = [&](float4_t (&E)[C::NJ], float4_t (&H)[C::NJ]) {
+    const int32_t n_rows = cur.e1 - cur.w0;                          // valid rows of this pass (<= 0: none)
+    int32_t seg_s = 0, seg_e = 0;                                    // phase 4's bounds, requested early
+    if constexpr (SEG) {
+      const int32_t r = cur.r0 + t / C::Q;
+      seg_s = rowptr[r < cur.r1 ? r : cur.r1];
+      seg_e = rowptr[r < cur.r1 ? r + 1 : cur.r1];
+    }
+    // the pass after this one
+    Pass fol = cur;
+    bool more = true;
+    if (cur.w0 + C::ROWS < cur.e1) {
+      fol.w0 = cur.w0 + C::ROWS;                                     // a tile longer than one pass
+    } else if (nxt.tile != cur.tile) {
+      fol = nxt;
+    } else {
+      more = false;                                                  // last pass: prefetch it again, unused
+    }
+    const int32_t rr_next = clamp_row(fol);
+    const int64_t pass_off = (int64_t)cur.w0 * F;
+
+    static_for<2 * C::KS>([&](auto ss) {
+      constexpr int si = decltype(ss)::value;
+      constexpr bool first = si < C::KS;                             // which contraction
+      constexpr int ks = first ? si : si - C::KS;
+      // ---- chunk si has landed (its DMA is two steps old); everything younger may stay in flight ------------
+      if constexpr (si == 0) wait_vm<0>();
+      else if constexpr (si == 1) wait_vm<C::DPW + V::of(0)>();
+      else wait_vm<V::of(si - 2) + C::DPW + V::of(si - 1)>();
+#if ABL != 2
+      __syncthreads();                                               // ... for every wave; slot - 1 is free
+#endif
+      if constexpr (si == C::KS) {
+        // the activation: hidden = act(acc + G1 rows + b1), in place; the second accumulators start at b2.
+        // BEFORE this step's DMAs: hipcc waits for the G1 rows with its own count, which does not know the
+        // DMAs and would drain the ones just issued with them
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) {
+          float4_t v = H[j] + *reinterpret_cast<const float4_t *>(bl + col(j));
+          if constexpr (M1 != kNone) v += rc[j];
+          H[j] = activate(v, act);
+          rc[j] = *reinterpret_cast<const float4_t *>(bl + F + col(j));
+        }
+      }
+      {
+        const int into = slot >= 1 ? slot - 1 : C::NSLOT - 1;        // (slot + 2) % 3
+#if ABL != 3 && ABL != 4
+        dma((si + 2) % (2 * C::KS), into);
+#else
+        (void)into;
+#endif
+      }
+      // ---- this step's B operand, from registers -----------------------------------------------------------
+      bf16x8 bh, bo;
+      if constexpr (first) split8(E[2 * ks], E[2 * ks + 1], bh, bo);
+      else split8(H[2 * ks], H[2 * ks + 1], bh, bo);
+      // ---- the loads that ride along (issued after the DMAs, counted by vis()) ---------------------------------
+      if constexpr (first) {
+        if constexpr (M1 != kNone && si < 4) {
+#pragma unroll
+          for (int j = si * (C::NJ / 4); j < (si + 1) * (C::NJ / 4); ++j)
+            rc[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G1) +
+                                                        ((uint32_t)i1 * ldb1 + col(j) * 4u));
+        }
+        if constexpr (RES == kResOther) {                            // E's registers are free: the residual rows
+          int row = prow < n_rows ? prow : (n_rows > 0 ? n_rows - 1 : 0);
+#pragma unroll
+          for (int j = 2 * ks; j < 2 * ks + 2; ++j)
+            E[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(res + pass_off) +
+                                                       (uint32_t)(row * F * 4 + col(j) * 4));
+        }
+      } else {
+        if constexpr (si == C::KS) {
+          i1n = rr_next;
+          i2n = rr_next;
+          if constexpr (M1 == kIdx) i1n = idx1[rr_next];
+          if constexpr (M2 == kIdx) i2n = idx2[rr_next];
+        }
+#pragma unroll
+        for (int j = 2 * ks; j < 2 * ks + 2; ++j)
+          H[j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr_next * F + col(j));
+      }
+      // ---- 16 column tiles x 3 products; W fragments from the ring ------------------------------------------
+      const char *wb = lds + slot * C::STEP + lane * 16;
+#pragma unroll
+      for (int jo = 0; jo < C::NJ; jo += 2) {
+#if ABL == 1 || ABL == 4
+        const int jr = 0;
+#else
+        const int jr = jo;
+#endif
+        const bf16x8 wh0 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2) * 1024);
+        const bf16x8 wl0 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 1) * 1024);
+        const bf16x8 wh1 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 2) * 1024);
+        const bf16x8 wl1 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 3) * 1024);
+        if constexpr (first) {
+          H[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bo, H[jo], 0, 0, 0);
+          H[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bo, H[jo + 1], 0, 0, 0);
+          H[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0, bh, H[jo], 0, 0, 0);
+          H[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1, bh, H[jo + 1], 0, 0, 0);
+          H[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bh, H[jo], 0, 0, 0);
+          H[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bh, H[jo + 1], 0, 0, 0);
+        } else {
+          rc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bo, rc[jo], 0, 0, 0);
+          rc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bo, rc[jo + 1], 0, 0, 0);
+          rc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0, bh, rc[jo], 0, 0, 0);
+          rc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1, bh, rc[jo + 1], 0, 0, 0);
+          rc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bh, rc[jo], 0, 0, 0);
+          rc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bh, rc[jo + 1], 0, 0, 0);
+        }
+      }
+      slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+    });
+
+    // ---- out = res + y, stored from registers ------------------------------------------------------------------
+    if (out && prow < n_rows) {
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j) {
+        float4_t o = rc[j];
+        if constexpr (RES != kResNone) o += E[j];
+        *reinterpret_cast<float4_t *>(reinterpret_cast<char *>(out + pass_off) +
+                                      (uint32_t)(prow * F * 4 + col(j) * 4)) = o;
+      }
+    }
+    // ---- E's registers take the next pass's G2 rows (its first contraction accumulates onto them) -------------
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) {
+      if constexpr (M2 != kNone)
+        E[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G2) +
+                                                   ((uint32_t)i2n * ldb2 + col(j) * 4u));
+      else
+        E[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- the messages of each target row, summed in stored order, 64 columns at a time ---------------------------
+    if constexpr (SEG) {
+      const int q = t % C::Q;
+      const int32_t w0 = cur.w0;
+      static_for<C::NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for<C::JC>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          *reinterpret_cast<float4_t *>(ytile + prow * C::PY + 16 * j + 4 * g) = rc[c * C::JC + j];
+        });
+        __syncthreads();
+        int32_t s = seg_s, en = seg_e;
+        for (int32_t r = cur.r0 + t / C::Q; r < cur.r1; r += C::SLOTS) {
+          if (r != cur.r0 + t / C::Q) {                              // a pass with more target rows than slots
+            s = rowptr[r];
+            en = rowptr[r + 1];
+          }
+          const int32_t lo = s > w0 ? s : w0;
+          const int32_t hi = en < w0 + C::ROWS ? en : w0 + C::ROWS;
+          float *dst = agg + (int64_t)r * F + c * C::YC + 4 * q;
+          if (lo < hi) {
+            float4_t acc = {0.f, 0.f, 0.f, 0.f};
+            if (s < w0) acc = *reinterpret_cast<const float4_t *>(dst);     // this block's own partial
+            for (int32_t e = lo; e < hi; ++e)
+              acc += *reinterpret_cast<const float4_t *>(ytile + (e - w0) * C::PY + 4 * q);
+            if (mean && hi == en) {
+              const float inv = 1.0f / (float)(en - s);
+              acc *= float4_t{inv, inv, inv, inv};
+            }
+            *reinterpret_cast<float4_t *>(dst) = acc;
+          } else if (s == en && w0 == cur.e0) {
+            *reinterpret_cast<float4_t *>(dst) = float4_t{0.f, 0.f, 0.f, 0.f};     // no in-edges
+          }
+        }
+        __syncthreads();
+      });
+    }
+    i1 = i1n;
+    i2 = i2n;
+    if (!more) {
+      last_pass = true;
+      return;
+    }
+    if (fol.tile != cur.tile) {                                      // moved on to the next tile: look one ahead
+      const int32_t tn = fol.tile + stride < t_hi ? fol.tile + stride : fol.tile;
+      span(tn, nxt);
+    }
+    cur = fol;
+  };
+
+  for (;;) {
+    pass_body(ra, rb);
+    if (last_pass) break;
+    pass_body(rb, ra);
+    if (last_pass) break;
+  }
+  wait_vm<0>();                                                      // the DMAs issued past the last chunk used
+}
+
+template <int F, int M1, int M2>
+int launch_rows(const float *A, const float *W1, const float *G1, const int32_t *idx1, const float *G2,
+                const int32_t *idx2, const float *b1, const float *W2, const float *b2, const float *res,
+                float *out, int64_t R, int act, const int32_t *rowptr, const int32_t *tile_row,
+                int64_t n_tiles, float *agg, int mean, void *workspace, uint32_t ldb1, uint32_t ldb2,
+                hipStream_t st) {
+  using C = RCfg<F>;
+  const bool seg = agg != nullptr;
+  bf16x8 *img = reinterpret_cast<bf16x8 *>(workspace);               // W1's k-steps, then W2's
+  k_split_wr<F><<<C::NJ * C::KS, 64, 0, st>>>(W1, img);
+  k_split_wr<F><<<C::NJ * C::KS, 64, 0, st>>>(W2, img + (int64_t)C::KS * (C::STEP / 16));
+  GWEN_LAUNCH_CHECK();
+  const int64_t tiles = seg ? n_tiles : (R + C::ROWS - 1) / C::ROWS;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    GWEN_HIP_CHECK(hipGetDevice(&dev));
+    GWEN_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = n < 8 ? 8 : n;
+  }
+  int64_t blocks = cus;                                              // one block per CU (130 KB of LDS)
+  if (blocks > tiles) blocks = tiles;
+  const int r = !res ? kResNone : (res == A ? kResA : kResOther);
+  const char *im = reinterpret_cast<const char *>(img);
+#define GWEN_R(SEGV, RV)                                                                              \
+  k_mlp2r<F, M1, M2, SEGV, RV><<<(unsigned)blocks, C::NW * 64, 0, st>>>(                              \
+      A, im, G1, idx1, G2, idx2, b1, b2, res, out, (int32_t)R, act, SEGV ? rowptr : nullptr,          \
+      SEGV ? tile_row : nullptr, (int32_t)tiles, SEGV ? agg : nullptr, SEGV ? mean : 0, ldb1, ldb2)
+  if (seg) {
+    if (r == kResNone) GWEN_R(true, kResNone); else if (r == kResA) GWEN_R(true, kResA); else GWEN_R(true, kResOther);
+  } else {
+    if (r == kResNone) GWEN_R(false, kResNone); else if (r == kResA) GWEN_R(false, kResA); else GWEN_R(false, kResOther);
+  }
+#undef GWEN_R
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+}  // namespace
+
+int gwen_mlp2_rows_f() { return RCfg<256>::ROWS; }
+
+// interact.hip's dispatch for F = 256 (pointers validated there); m1 / m2 as interact.hip's kNone / kSelf / kIdx
+int gwen_mlp2_rows_launch(int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,
+                          const float *G2, const int32_t *idx2, const float *b1, const float *W2,
+                          const float *b2, const float *res, float *out, int64_t R, int act,
+                          const int32_t *rowptr, const int32_t *tile_row, int64_t n_tiles, float *agg,
+                          int mean, void *workspace, uint32_t ldb1, uint32_t ldb2, hipStream_t st) {
+#define GWEN_MODE(A1, A2)                                                                             \
+  if (m1 == A1 && m2 == A2)                                                                           \
+    return launch_rows<256, A1, A2>(A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr,  \
+                                    tile_row, n_tiles, agg, mean, workspace, ldb1, ldb2, st)
+  GWEN_MODE(kNone, kNone); GWEN_MODE(kSelf, kNone); GWEN_MODE(kIdx, kNone); GWEN_MODE(kIdx, kIdx);
+#undef GWEN_MODE
+  return GWEN_EINVAL;
+}

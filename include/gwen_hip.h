@@ -422,7 +422,7 @@ int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_la
  *   F = 256 needs one -- its weights do not fit the register file and are streamed as bf16 images.
  *
  * gwen_edge_tiles: row-aligned tiling of a CSR's entries.  tile c owns the target rows whose first
- *   entry lies in [cT, (c+1)T); n_tiles = gwen_edge_tiles_count(E, T) = max(1, ceil(E/T)); T <= 64.
+ *   entry lies in [cT, (c+1)T); n_tiles = gwen_edge_tiles_count(E, T) = max(1, ceil(E/T)); T <= 128.
  *   T = gwen_mlp2_rows(F) - (max row length - 1) (at least 1) keeps each tile a single pass of the
  *   kernel at width F; any T is correct (longer tiles take several passes).
  *   Also writes dst[e] = target row of entry e (int32 [E]) -- idx2 of the edge MLP.
@@ -431,7 +431,7 @@ int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_la
 #define GWEN_ACT_RELU 1
 #define GWEN_ACT_SILU 2
 int gwen_mlp2_supported(int64_t F);          /* F in {32, 64, 128, 256} */
-int gwen_mlp2_rows(int64_t F);                /* rows one pass of the kernel takes at width F (64 or 32) */
+int gwen_mlp2_rows(int64_t F);                /* rows one pass of the kernel takes at width F (64; 128 at F = 256) */
 int64_t gwen_mlp2_workspace_bytes(int64_t F); /* F = 256: room for the pre-split weight images; else 0 */
 int64_t gwen_edge_tiles_count(int64_t E, int64_t T);
 int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int64_t T, int32_t *tile_row,
