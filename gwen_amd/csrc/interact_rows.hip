@@ -31,7 +31,18 @@
 #include "common.h"
 #include <type_traits>
 #ifndef ABL
-#define ABL 0
+#define ABL 0     // timing ablations (tools/experiments/abl_k6r.sh); results are wrong by construction for ABL != 0
+#endif
+#ifdef GWEN_K6R_STAMPS   // diagnostic build only (tools/experiments/k6r_stamps.py): s_memtime per phase and wave
+__device__ uint64_t *g_k6r_stamps = nullptr;
+#define STAMP_DECL uint64_t tacc[8] = {}; uint64_t tprev = __builtin_amdgcn_s_memtime()
+#define STAMP(k) do { const uint64_t tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } while (0)
+#define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0 && g_k6r_stamps) for (int k = 0; k < 8; ++k) \
+    g_k6r_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = tacc[k]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
 #endif
 
 namespace {
@@ -76,12 +87,14 @@ __device__ inline const char *uniform_ptr(const void *p) {
   return reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
 }
 
-// one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) to LDS byte address dst + 16 l
+// one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) + IMM to LDS byte address dst + IMM + 16 l
+template <int IMM>
 __device__ inline void glds16(const void *base, uint32_t voff, uint32_t dst) {
+  static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
   uint32_t keep;       // M0 is compiler-reserved: save and restore it inside the statement
   asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+               "global_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst), "n"(IMM) : "memory");
 }
 
 template <int N>
@@ -202,11 +215,19 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
   // ---- the weight ring: chunk c (0 .. 2 KS - 1: W1's k-steps, then W2's) is the same for every pass ---------
   const char *img_w = uniform_ptr(img + (int64_t)wave * C::DPW * 1024);
   int slot = 0;                                                      // slot of the chunk the next step consumes
+  const uint32_t lane16 = (uint32_t)lane * 16;
+  // (the chunk's offset is added to the scalar base behind an opaque asm and the piece's goes into the
+  //  instruction's immediate: left to hipcc, the 64 loop-invariant per-lane offsets -- or the 64 scalar bases --
+  //  are hoisted out of the pass loop into registers of their own, and spilled)
   auto dma = [&](int chunk, int into) {                              // this wave's share of one chunk
-#pragma unroll
-    for (int q = 0; q < C::DPW; ++q)
-      glds16(img_w, (uint32_t)(chunk * C::STEP + q * 1024 + lane * 16),
-             __builtin_amdgcn_readfirstlane(lds0 + into * C::STEP + (wave * C::DPW + q) * 1024));
+    uint32_t off = (uint32_t)chunk * C::STEP;
+    asm volatile("" : "+s"(off));
+    const char *src = img_w + off;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + into * C::STEP + wave * C::DPW * 1024);
+    static_for<C::DPW>([&](auto qq) {
+      constexpr int q = decltype(qq)::value;
+      glds16<q * 1024>(src, lane16, dst);       // the immediate offset applies to the global AND the LDS address
+    });
   };
 
   float4_t ra[C::NJ], rb[C::NJ], rc[C::NJ];
@@ -239,6 +260,7 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
   using V = Vis<F, M1, M2, RES>;
 
   bool last_pass = false;
+  STAMP_DECL;
   // One pass.  E: this pass's A rows (later the residual).  H: pre-loaded with the G2 rows (or zero) -- the first
   // contraction accumulates onto it, the activation turns it into the hidden layer, the second contraction
   // consumes it and the NEXT pass's A rows move in.  rc: G1 rows, then the second contraction's accumulators.
@@ -267,17 +289,26 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
       constexpr int si = decltype(ss)::value;
       constexpr bool first = si < C::KS;                             // which contraction
       constexpr int ks = first ? si : si - C::KS;
+      // this step's view of the lane's column offset: opaque, or hipcc keeps 16 loop-invariant offsets per
+      // table live across the whole pass loop (and spills them)
+      int gs = g;
+      asm volatile("" : "+v"(gs));
+      auto col = [&](int j) { return 16 * j + 4 * gs; };
       // ---- chunk si has landed (its DMA is two steps old); everything younger may stay in flight ------------
       if constexpr (si == 0) wait_vm<0>();
       else if constexpr (si == 1) wait_vm<C::DPW + V::of(0)>();
       else wait_vm<V::of(si - 2) + C::DPW + V::of(si - 1)>();
+      STAMP(si == 0 ? 0 : 1);
 #if ABL != 2
       __syncthreads();                                               // ... for every wave; slot - 1 is free
 #endif
+      STAMP(2);
       if constexpr (si == C::KS) {
         // the activation: hidden = act(acc + G1 rows + b1), in place; the second accumulators start at b2.
         // BEFORE this step's DMAs: hipcc waits for the G1 rows with its own count, which does not know the
-        // DMAs and would drain the ones just issued with them
+        // DMAs and would drain the ones just issued with them.  (Both waves of a SIMD are here at once: ~8 000
+        // cycles a pass.  Activating tile by tile in the steps that consume the tiles, beside the other wave's
+        // MFMAs, needs ~10 more registers than the 256 there are: 150-220 spilled, slower.)
 #pragma unroll
         for (int j = 0; j < C::NJ; ++j) {
           float4_t v = H[j] + *reinterpret_cast<const float4_t *>(bl + col(j));
@@ -301,17 +332,17 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
       // ---- the loads that ride along (issued after the DMAs, counted by vis()) ---------------------------------
       if constexpr (first) {
         if constexpr (M1 != kNone && si < 4) {
+          const char *p1 = reinterpret_cast<const char *>(G1) + ((uint32_t)i1 * ldb1 + 16u * gs);
 #pragma unroll
           for (int j = si * (C::NJ / 4); j < (si + 1) * (C::NJ / 4); ++j)
-            rc[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G1) +
-                                                        ((uint32_t)i1 * ldb1 + col(j) * 4u));
+            rc[j] = *reinterpret_cast<const float4_t *>(p1 + 64 * j);
         }
         if constexpr (RES == kResOther) {                            // E's registers are free: the residual rows
           int row = prow < n_rows ? prow : (n_rows > 0 ? n_rows - 1 : 0);
+          const char *pr = reinterpret_cast<const char *>(res + pass_off) + (uint32_t)(row * F * 4 + 16 * gs);
 #pragma unroll
           for (int j = 2 * ks; j < 2 * ks + 2; ++j)
-            E[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(res + pass_off) +
-                                                       (uint32_t)(row * F * 4 + col(j) * 4));
+            E[j] = *reinterpret_cast<const float4_t *>(pr + 64 * j);
         }
       } else {
         if constexpr (si == C::KS) {
@@ -320,9 +351,10 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
           if constexpr (M1 == kIdx) i1n = idx1[rr_next];
           if constexpr (M2 == kIdx) i2n = idx2[rr_next];
         }
+        const char *pa = reinterpret_cast<const char *>(A + (int64_t)rr_next * F) + 16 * gs;
 #pragma unroll
         for (int j = 2 * ks; j < 2 * ks + 2; ++j)
-          H[j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr_next * F + col(j));
+          H[j] = *reinterpret_cast<const float4_t *>(pa + 64 * j);
       }
       // ---- 16 column tiles x 3 products; W fragments from the ring ------------------------------------------
       const char *wb = lds + slot * C::STEP + lane * 16;
@@ -354,28 +386,36 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
         }
       }
       slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+      STAMP(si == C::KS ? 4 : 3);
     });
 
-    // ---- out = res + y, stored from registers ------------------------------------------------------------------
-    if (out && prow < n_rows) {
+    // ---- out = res + y stored from registers; E's registers then take the next pass's G2 rows (its first
+    // contraction accumulates onto them).  (Issued in four parts inside the aggregation's chunks instead:
+    // 679 -> 701 us.) --------------------------------------------------------------------------------------------
+    {
+      constexpr int j0 = 0, n = C::NJ;
+      int gs = g, ps = prow;
+      asm volatile("" : "+v"(gs), "+v"(ps));
+      if (out && prow < n_rows) {
+        char *po = reinterpret_cast<char *>(out + pass_off) + (uint32_t)(ps * F * 4 + 16 * gs);
 #pragma unroll
-      for (int j = 0; j < C::NJ; ++j) {
-        float4_t o = rc[j];
-        if constexpr (RES != kResNone) o += E[j];
-        *reinterpret_cast<float4_t *>(reinterpret_cast<char *>(out + pass_off) +
-                                      (uint32_t)(prow * F * 4 + col(j) * 4)) = o;
+        for (int j = j0; j < j0 + n; ++j) {
+          float4_t o = rc[j];
+          if constexpr (RES != kResNone) o += E[j];
+          *reinterpret_cast<float4_t *>(po + 64 * j) = o;
+        }
+      }
+      const char *p2 = reinterpret_cast<const char *>(G2) + ((uint32_t)i2n * ldb2 + 16u * gs);
+#pragma unroll
+      for (int j = j0; j < j0 + n; ++j) {
+        if constexpr (M2 != kNone)
+          E[j] = *reinterpret_cast<const float4_t *>(p2 + 64 * j);
+        else
+          E[j] = float4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
-    // ---- E's registers take the next pass's G2 rows (its first contraction accumulates onto them) -------------
-#pragma unroll
-    for (int j = 0; j < C::NJ; ++j) {
-      if constexpr (M2 != kNone)
-        E[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G2) +
-                                                   ((uint32_t)i2n * ldb2 + col(j) * 4u));
-      else
-        E[j] = float4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    // ---- the messages of each target row, summed in stored order, 64 columns at a time ---------------------------
+    STAMP(5);
+    // ---- the messages of each target row, summed in stored order, 64 columns at a time -------------------------
     if constexpr (SEG) {
       const int q = t % C::Q;
       const int32_t w0 = cur.w0;
@@ -386,6 +426,7 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
           *reinterpret_cast<float4_t *>(ytile + prow * C::PY + 16 * j + 4 * g) = rc[c * C::JC + j];
         });
         __syncthreads();
+        STAMP(6);
         int32_t s = seg_s, en = seg_e;
         for (int32_t r = cur.r0 + t / C::Q; r < cur.r1; r += C::SLOTS) {
           if (r != cur.r0 + t / C::Q) {                              // a pass with more target rows than slots
@@ -409,7 +450,9 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
             *reinterpret_cast<float4_t *>(dst) = float4_t{0.f, 0.f, 0.f, 0.f};     // no in-edges
           }
         }
+        STAMP(7);
         __syncthreads();
+        STAMP(5);
       });
     }
     i1 = i1n;
@@ -432,6 +475,7 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
     if (last_pass) break;
   }
   wait_vm<0>();                                                      // the DMAs issued past the last chunk used
+  STAMP_FLUSH;
 }
 
 template <int F, int M1, int M2>
@@ -471,6 +515,12 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
+
+#ifdef GWEN_K6R_STAMPS
+}
+extern "C" int gwen_k6r_set_stamps(uint64_t *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k6r_stamps), &p, sizeof(p)); }
+namespace {
+#endif
 
 }  // namespace
 
