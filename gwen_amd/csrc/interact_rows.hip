@@ -30,6 +30,9 @@
 // (the first contraction accumulates onto them), so the pass body exists twice with the two sets swapped.
 #include "common.h"
 #include <type_traits>
+#ifndef K6R_RT
+#define K6R_RT 1      // 16-row tiles per wave (see RCfg)
+#endif
 #ifndef ABL
 #define ABL 0     // timing ablations (tools/experiments/abl_k6r.sh); results are wrong by construction for ABL != 0
 #endif
@@ -38,7 +41,7 @@ __device__ uint64_t *g_k6r_stamps = nullptr;
 #define STAMP_DECL uint64_t tacc[8] = {}; uint64_t tprev = __builtin_amdgcn_s_memtime()
 #define STAMP(k) do { const uint64_t tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } while (0)
 #define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0 && g_k6r_stamps) for (int k = 0; k < 8; ++k) \
-    g_k6r_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = tacc[k]; } while (0)
+    g_k6r_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = tacc[k]; } while (0)   /* waves 4-7 stay 0 at RT = 2 */
 #else
 #define STAMP_DECL
 #define STAMP(k)
@@ -53,12 +56,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kNone = 0, kSelf = 1, kIdx = 2;      // how a table is addressed (as interact.hip)
 constexpr int kResNone = 0, kResA = 1, kResOther = 2;
 
-template <int F>
+// RT = 16-row tiles per wave: 1 -> 8 waves (two per SIMD, 256 registers each) -- what runs; 2 -> 4 waves (one per
+// SIMD, 512 registers, every W fragment read from LDS feeds two row tiles): hipcc spills 130-230 registers of the
+// three 128-register sets and the edge kernel takes 1 006 us instead of 679 (tools/experiments/abl_k6r.sh)
+template <int F, int RT = 1>
 struct RCfg {
   static constexpr int NJ = F / 16;                 // column tiles = float4 registers per row and set
   static constexpr int KS = F / 32;                 // k-steps per contraction
-  static constexpr int NW = 8;                      // waves per block
-  static constexpr int ROWS = NW * 16;              // rows per pass
+  static constexpr int NW = 8 / RT;                 // waves per block
+  static constexpr int ROWS = NW * RT * 16;         // rows per pass: 128
   static constexpr int STEP = NJ * 2 * 1024;        // bytes of W fragments per k-step: (tile, hi/lo) x 1 KB
   static constexpr int NSLOT = 3;
   static constexpr int DPW = STEP / 1024 / NW;      // DMA instructions per wave and k-step
@@ -69,6 +75,8 @@ struct RCfg {
   static constexpr int lds_bytes = kOffB + 2 * F * 4;
   static constexpr int Q = YC / 4;                  // 16-B pieces per chunk row
   static constexpr int SLOTS = NW * 64 / Q;         // target rows reduced at a time
+  static constexpr int JG = 2 / RT;                 // column tiles per MFMA group (two accumulators a group)
+  static_assert(RT == 1 || RT == 2, "one or two row tiles per wave");
   static_assert(STEP % (1024 * NW) == 0 && lds_bytes <= 160 * 1024, "ring must tile over the waves and fit");
 };
 
@@ -148,24 +156,25 @@ struct Pass {
 // visible (hipcc-counted) vector-memory instructions step si of a pass issues after its DMAs: the first
 // contraction's steps load the G1 rows (4 tiles a step, steps 0-3) and, with a residual other than A, its rows;
 // the second one's load the next pass's A rows (2 tiles a step) and, in its first step, the next indices
-template <int F, int M1, int M2, int RES>
+template <int F, int RT, int M1, int M2, int RES>
 struct Vis {
   static constexpr int of(int si) {
-    using C = RCfg<F>;
-    if (si < C::KS) return ((M1 != kNone && si < 4) ? C::NJ / 4 : 0) + (RES == kResOther ? 2 : 0);
-    return 2 + (si == C::KS ? (M1 == kIdx ? 1 : 0) + (M2 == kIdx ? 1 : 0) : 0);
+    using C = RCfg<F, RT>;
+    if (si < C::KS) return RT * (((M1 != kNone && si < 4) ? C::NJ / 4 : 0) + (RES == kResOther ? 2 : 0));
+    return RT * (2 + (si == C::KS ? (M1 == kIdx ? 1 : 0) + (M2 == kIdx ? 1 : 0) : 0));
   }
 };
 
-template <int F, int M1, int M2, bool SEG, int RES>
-__global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
+template <int F, int RT, int M1, int M2, bool SEG, int RES>
+__global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
     const float *__restrict__ A, const char *__restrict__ img, const float *__restrict__ G1,
     const int32_t *__restrict__ idx1, const float *__restrict__ G2, const int32_t *__restrict__ idx2,
     const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ res,
     float *__restrict__ out, int32_t R, int act, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ tile_row, int32_t n_tiles, float *__restrict__ agg, int mean,
     uint32_t ldb1, uint32_t ldb2) {
-  using C = RCfg<F>;
+  using C = RCfg<F, RT>;
+  constexpr int NR = RT * C::NJ;                                     // float4 registers per set
   __shared__ __attribute__((aligned(1024))) char lds[C::lds_bytes];
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   float *ytile = reinterpret_cast<float *>(lds + C::kOffY);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mi = lane & 15, g = lane >> 4;
-  const int prow = wave * 16 + mi;                                   // this lane's row within a pass
+  auto prow = [&](int rt) { return (wave * RT + rt) * 16 + mi; };    // this lane's rows within a pass
   auto col = [&](int j) { return 16 * j + 4 * g; };                  // its 4 columns of column tile j
 
   for (int f = t; f < F; f += C::NW * 64) {
@@ -205,8 +214,8 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
     p.w0 = p.e0;
   };
   // rows beyond the pass are clamped to its last row (always a valid row: R >= 1)
-  auto clamp_row = [&](const Pass &p) {
-    int32_t rr = p.w0 + prow;
+  auto clamp_row = [&](const Pass &p, int rt) {
+    int32_t rr = p.w0 + prow(rt);
     const int32_t last = (p.e1 < R ? p.e1 : R) - 1;
     rr = rr < last ? rr : last;
     return rr < 0 ? 0 : rr;
@@ -226,13 +235,14 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + into * C::STEP + wave * C::DPW * 1024);
     static_for<C::DPW>([&](auto qq) {
       constexpr int q = decltype(qq)::value;
-      glds16<q * 1024>(src, lane16, dst);       // the immediate offset applies to the global AND the LDS address
+      // the immediate offset (< 4096) applies to the global AND the LDS address
+      glds16<(q % 4) * 1024>(src + (q / 4) * 4096, lane16, dst + (q / 4) * 4096);
     });
   };
 
-  float4_t ra[C::NJ], rb[C::NJ], rc[C::NJ];
-  int32_t i1 = 0, i2 = 0;                                            // table rows of the CURRENT pass's row
-  int32_t i1n = 0, i2n = 0;                                          // ... of the next pass's
+  float4_t ra[NR], rb[NR], rc[NR];
+  int32_t i1[RT], i2[RT];                                            // table rows of the CURRENT pass's rows
+  int32_t i1n[RT], i2n[RT];                                          // ... of the next pass's
 
   Pass cur, nxt;
   span(tile0, cur);
@@ -240,31 +250,33 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
     const int32_t tn = tile0 + stride < t_hi ? tile0 + stride : tile0;
     span(tn, nxt);
   }
-  {                                                                  // first pass: rows, indices, G2 rows
-    const int32_t rr = clamp_row(cur);
-    i1 = M1 == kIdx ? idx1[rr] : rr;
-    i2 = M2 == kIdx ? idx2[rr] : rr;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {                                  // first pass: rows, indices, G2 rows
+    const int32_t rr = clamp_row(cur, rt);
+    i1[rt] = M1 == kIdx ? idx1[rr] : rr;
+    i2[rt] = M2 == kIdx ? idx2[rr] : rr;
+    i1n[rt] = i2n[rt] = 0;
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j) {
-      ra[j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + col(j));
+      ra[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + col(j));
       if constexpr (M2 != kNone)
-        rb[j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G2) +
-                                                    ((uint32_t)i2 * ldb2 + col(j) * 4u));
+        rb[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G2) +
+                                                                 ((uint32_t)i2[rt] * ldb2 + col(j) * 4u));
       else
-        rb[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        rb[rt * C::NJ + j] = float4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
   dma(0, 0);
   dma(1, 1);
 
-  using V = Vis<F, M1, M2, RES>;
+  using V = Vis<F, RT, M1, M2, RES>;
 
   bool last_pass = false;
   STAMP_DECL;
   // One pass.  E: this pass's A rows (later the residual).  H: pre-loaded with the G2 rows (or zero) -- the first
   // contraction accumulates onto it, the activation turns it into the hidden layer, the second contraction
   // consumes it and the NEXT pass's A rows move in.  rc: G1 rows, then the second contraction's accumulators.
-  auto pass_body = [&](float4_t (&E)[C::NJ], float4_t (&H)[C::NJ]) {
+  auto pass_body = [&](float4_t (&E)[NR], float4_t (&H)[NR]) {
     const int32_t n_rows = cur.e1 - cur.w0;                          // valid rows of this pass (<= 0: none)
     int32_t seg_s = 0, seg_e = 0;                                    // phase 4's bounds, requested early
     if constexpr (SEG) {
@@ -282,7 +294,9 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
     } else {
       more = false;                                                  // last pass: prefetch it again, unused
     }
-    const int32_t rr_next = clamp_row(fol);
+    int32_t rr_next[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) rr_next[rt] = clamp_row(fol, rt);
     const int64_t pass_off = (int64_t)cur.w0 * F;
 
     static_for<2 * C::KS>([&](auto ss) {
@@ -310,12 +324,14 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
         // cycles a pass.  Activating tile by tile in the steps that consume the tiles, beside the other wave's
         // MFMAs, needs ~10 more registers than the 256 there are: 150-220 spilled, slower.)
 #pragma unroll
-        for (int j = 0; j < C::NJ; ++j) {
-          float4_t v = H[j] + *reinterpret_cast<const float4_t *>(bl + col(j));
-          if constexpr (M1 != kNone) v += rc[j];
-          H[j] = activate(v, act);
-          rc[j] = *reinterpret_cast<const float4_t *>(bl + F + col(j));
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) {
+            float4_t v = H[rt * C::NJ + j] + *reinterpret_cast<const float4_t *>(bl + col(j));
+            if constexpr (M1 != kNone) v += rc[rt * C::NJ + j];
+            H[rt * C::NJ + j] = activate(v, act);
+            rc[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(bl + F + col(j));
+          }
       }
       {
         const int into = slot >= 1 ? slot - 1 : C::NSLOT - 1;        // (slot + 2) % 3
@@ -325,65 +341,73 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
         (void)into;
 #endif
       }
-      // ---- this step's B operand, from registers -----------------------------------------------------------
-      bf16x8 bh, bo;
-      if constexpr (first) split8(E[2 * ks], E[2 * ks + 1], bh, bo);
-      else split8(H[2 * ks], H[2 * ks + 1], bh, bo);
-      // ---- the loads that ride along (issued after the DMAs, counted by vis()) ---------------------------------
-      if constexpr (first) {
-        if constexpr (M1 != kNone && si < 4) {
-          const char *p1 = reinterpret_cast<const char *>(G1) + ((uint32_t)i1 * ldb1 + 16u * gs);
+      // ---- this step's B operands, from registers ----------------------------------------------------------
+      bf16x8 bh[RT], bo[RT];
 #pragma unroll
-          for (int j = si * (C::NJ / 4); j < (si + 1) * (C::NJ / 4); ++j)
-            rc[j] = *reinterpret_cast<const float4_t *>(p1 + 64 * j);
+      for (int rt = 0; rt < RT; ++rt) {
+        if constexpr (first) {
+          split8(E[rt * C::NJ + 2 * ks], E[rt * C::NJ + 2 * ks + 1], bh[rt], bo[rt]);
+        } else {
+          split8(H[rt * C::NJ + 2 * ks], H[rt * C::NJ + 2 * ks + 1], bh[rt], bo[rt]);
         }
-        if constexpr (RES == kResOther) {                            // E's registers are free: the residual rows
-          int row = prow < n_rows ? prow : (n_rows > 0 ? n_rows - 1 : 0);
-          const char *pr = reinterpret_cast<const char *>(res + pass_off) + (uint32_t)(row * F * 4 + 16 * gs);
+      }
+      // ---- the loads that ride along (issued after the DMAs, counted by vis()) ---------------------------------
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if constexpr (first) {
+          if constexpr (M1 != kNone && si < 4) {
+            const char *p1 = reinterpret_cast<const char *>(G1) + ((uint32_t)i1[rt] * ldb1 + 16u * gs);
+#pragma unroll
+            for (int j = si * (C::NJ / 4); j < (si + 1) * (C::NJ / 4); ++j)
+              rc[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(p1 + 64 * j);
+          }
+          if constexpr (RES == kResOther) {                          // E's registers are free: the residual rows
+            int row = prow(rt) < n_rows ? prow(rt) : (n_rows > 0 ? n_rows - 1 : 0);
+            const char *pr = reinterpret_cast<const char *>(res + pass_off) + (uint32_t)(row * F * 4 + 16 * gs);
+#pragma unroll
+            for (int j = 2 * ks; j < 2 * ks + 2; ++j)
+              E[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(pr + 64 * j);
+          }
+        } else {
+          if constexpr (si == C::KS) {
+            i1n[rt] = rr_next[rt];
+            i2n[rt] = rr_next[rt];
+            if constexpr (M1 == kIdx) i1n[rt] = idx1[rr_next[rt]];
+            if constexpr (M2 == kIdx) i2n[rt] = idx2[rr_next[rt]];
+          }
+          const char *pa = reinterpret_cast<const char *>(A + (int64_t)rr_next[rt] * F) + 16 * gs;
 #pragma unroll
           for (int j = 2 * ks; j < 2 * ks + 2; ++j)
-            E[j] = *reinterpret_cast<const float4_t *>(pr + 64 * j);
+            H[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(pa + 64 * j);
         }
-      } else {
-        if constexpr (si == C::KS) {
-          i1n = rr_next;
-          i2n = rr_next;
-          if constexpr (M1 == kIdx) i1n = idx1[rr_next];
-          if constexpr (M2 == kIdx) i2n = idx2[rr_next];
-        }
-        const char *pa = reinterpret_cast<const char *>(A + (int64_t)rr_next * F) + 16 * gs;
-#pragma unroll
-        for (int j = 2 * ks; j < 2 * ks + 2; ++j)
-          H[j] = *reinterpret_cast<const float4_t *>(pa + 64 * j);
       }
-      // ---- 16 column tiles x 3 products; W fragments from the ring ------------------------------------------
+      // ---- 16 column tiles x RT row tiles x 3 products; W fragments from the ring, two accumulators a group ----
       const char *wb = lds + slot * C::STEP + lane * 16;
 #pragma unroll
-      for (int jo = 0; jo < C::NJ; jo += 2) {
+      for (int jo = 0; jo < C::NJ; jo += C::JG) {
+        bf16x8 wh[C::JG], wl[C::JG];
+#pragma unroll
+        for (int d = 0; d < C::JG; ++d) {
 #if ABL == 1 || ABL == 4
-        const int jr = 0;
+          const int jr = 0;
 #else
-        const int jr = jo;
+          const int jr = jo + d;
 #endif
-        const bf16x8 wh0 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2) * 1024);
-        const bf16x8 wl0 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 1) * 1024);
-        const bf16x8 wh1 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 2) * 1024);
-        const bf16x8 wl1 = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 3) * 1024);
-        if constexpr (first) {
-          H[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bo, H[jo], 0, 0, 0);
-          H[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bo, H[jo + 1], 0, 0, 0);
-          H[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0, bh, H[jo], 0, 0, 0);
-          H[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1, bh, H[jo + 1], 0, 0, 0);
-          H[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bh, H[jo], 0, 0, 0);
-          H[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bh, H[jo + 1], 0, 0, 0);
-        } else {
-          rc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bo, rc[jo], 0, 0, 0);
-          rc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bo, rc[jo + 1], 0, 0, 0);
-          rc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0, bh, rc[jo], 0, 0, 0);
-          rc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1, bh, rc[jo + 1], 0, 0, 0);
-          rc[jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0, bh, rc[jo], 0, 0, 0);
-          rc[jo + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1, bh, rc[jo + 1], 0, 0, 0);
+          wh[d] = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2) * 1024);
+          wl[d] = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 1) * 1024);
         }
+#pragma unroll
+        for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+          for (int d = 0; d < C::JG; ++d)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              const bf16x8 wa = kind == 1 ? wl[d] : wh[d];
+              const bf16x8 xb = kind == 0 ? bo[rt] : bh[rt];
+              const int ix = rt * C::NJ + jo + d;
+              if constexpr (first) H[ix] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, H[ix], 0, 0, 0);
+              else rc[ix] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, rc[ix], 0, 0, 0);
+            }
       }
       slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
       STAMP(si == C::KS ? 4 : 3);
@@ -392,26 +416,26 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
     // ---- out = res + y stored from registers; E's registers then take the next pass's G2 rows (its first
     // contraction accumulates onto them).  (Issued in four parts inside the aggregation's chunks instead:
     // 679 -> 701 us.) --------------------------------------------------------------------------------------------
-    {
-      constexpr int j0 = 0, n = C::NJ;
-      int gs = g, ps = prow;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      int gs = g, ps = prow(rt);
       asm volatile("" : "+v"(gs), "+v"(ps));
-      if (out && prow < n_rows) {
+      if (out && prow(rt) < n_rows) {
         char *po = reinterpret_cast<char *>(out + pass_off) + (uint32_t)(ps * F * 4 + 16 * gs);
 #pragma unroll
-        for (int j = j0; j < j0 + n; ++j) {
-          float4_t o = rc[j];
-          if constexpr (RES != kResNone) o += E[j];
+        for (int j = 0; j < C::NJ; ++j) {
+          float4_t o = rc[rt * C::NJ + j];
+          if constexpr (RES != kResNone) o += E[rt * C::NJ + j];
           *reinterpret_cast<float4_t *>(po + 64 * j) = o;
         }
       }
-      const char *p2 = reinterpret_cast<const char *>(G2) + ((uint32_t)i2n * ldb2 + 16u * gs);
+      const char *p2 = reinterpret_cast<const char *>(G2) + ((uint32_t)i2n[rt] * ldb2 + 16u * gs);
 #pragma unroll
-      for (int j = j0; j < j0 + n; ++j) {
+      for (int j = 0; j < C::NJ; ++j) {
         if constexpr (M2 != kNone)
-          E[j] = *reinterpret_cast<const float4_t *>(p2 + 64 * j);
+          E[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(p2 + 64 * j);
         else
-          E[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+          E[rt * C::NJ + j] = float4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
     STAMP(5);
@@ -421,10 +445,11 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
       const int32_t w0 = cur.w0;
       static_for<C::NCH>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        static_for<C::JC>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          *reinterpret_cast<float4_t *>(ytile + prow * C::PY + 16 * j + 4 * g) = rc[c * C::JC + j];
-        });
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int j = 0; j < C::JC; ++j)
+            *reinterpret_cast<float4_t *>(ytile + prow(rt) * C::PY + 16 * j + 4 * g) = rc[rt * C::NJ + c * C::JC + j];
         __syncthreads();
         STAMP(6);
         int32_t s = seg_s, en = seg_e;
@@ -455,8 +480,11 @@ __global__ __launch_bounds__(RCfg<F>::NW * 64) void k_mlp2r(
         STAMP(5);
       });
     }
-    i1 = i1n;
-    i2 = i2n;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      i1[rt] = i1n[rt];
+      i2[rt] = i2n[rt];
+    }
     if (!more) {
       last_pass = true;
       return;
@@ -484,7 +512,7 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
                 float *out, int64_t R, int act, const int32_t *rowptr, const int32_t *tile_row,
                 int64_t n_tiles, float *agg, int mean, void *workspace, uint32_t ldb1, uint32_t ldb2,
                 hipStream_t st) {
-  using C = RCfg<F>;
+  using C = RCfg<F, K6R_RT>;
   const bool seg = agg != nullptr;
   bf16x8 *img = reinterpret_cast<bf16x8 *>(workspace);               // W1's k-steps, then W2's
   k_split_wr<F><<<C::NJ * C::KS, 64, 0, st>>>(W1, img);
@@ -503,7 +531,7 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
   const int r = !res ? kResNone : (res == A ? kResA : kResOther);
   const char *im = reinterpret_cast<const char *>(img);
 #define GWEN_R(SEGV, RV)                                                                              \
-  k_mlp2r<F, M1, M2, SEGV, RV><<<(unsigned)blocks, C::NW * 64, 0, st>>>(                              \
+  k_mlp2r<F, K6R_RT, M1, M2, SEGV, RV><<<(unsigned)blocks, C::NW * 64, 0, st>>>(                              \
       A, im, G1, idx1, G2, idx2, b1, b2, res, out, (int32_t)R, act, SEGV ? rowptr : nullptr,          \
       SEGV ? tile_row : nullptr, (int32_t)tiles, SEGV ? agg : nullptr, SEGV ? mean : 0, ldb1, ldb2)
   if (seg) {
@@ -524,7 +552,7 @@ namespace {
 
 }  // namespace
 
-int gwen_mlp2_rows_f() { return RCfg<256>::ROWS; }
+int gwen_mlp2_rows_f() { return RCfg<256, K6R_RT>::ROWS; }
 
 // interact.hip's dispatch for F = 256 (pointers validated there); m1 / m2 as interact.hip's kNone / kSelf / kIdx
 int gwen_mlp2_rows_launch(int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,

@@ -6,9 +6,7 @@ while read -r flags; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gwen_amd/libgwen_hip.so $(ls gwen_amd/build/*.o | grep -v interact_rows) /tmp/ir_v.o
   echo "== $flags"; timeout -k 10 200 python3 tools/inet_bench.py --channels 256 --reorder hilbert 2>&1 | tail -5 | head -4 | cut -c1-48
 done <<VARIANTS
--DTAIL_V2=1 -DSUM4=1 -DACT_BF=1
--DTAIL_V2=0 -DSUM4=1 -DACT_BF=1
--DTAIL_V2=0 -DSUM4=0 -DACT_BF=1
--DTAIL_V2=0 -DSUM4=0 -DACT_BF=0
--DTAIL_V2=1 -DSUM4=0 -DACT_BF=0
+-DK6R_RT=1
+-DK6R_RT=2
+-DK6R_RT=2 -DLAZY_ACT=1
 VARIANTS
