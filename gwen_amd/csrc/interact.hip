@@ -17,7 +17,9 @@
 //   and W2 in registers as 3xbf16 fragments (hi/lo, see layer.hip) with W as the MFMA A operand, so a lane
 //   ends up with 4 consecutive columns of one row (16-B gathers, 16-B stores).  At 256 channels the
 //   fragments (512 KB) exceed the register file: that width runs on the row-stationary kernel of
-//   interact_rows.hip instead (weights streamed through an LDS ring, activations in registers);
+//   interact_rows.hip instead (weights streamed through an LDS ring, activations in registers), and so does
+//   64 channels (weights resident in LDS, rows read and written 256 contiguous bytes at a time): this kernel
+//   serves 32 and 128 channels;
 //   phase 1  A rows, prefetched during the previous pass in the OUTPUT layout (the residual stays in
 //            registers) -> hi/lo bf16 LDS tile;
 //   phase 2  pre = MFMA + gathered addends + b1, activation -> hi/lo hidden tile (its own LDS image);
@@ -487,7 +489,7 @@ int launch_mode(int m1, int m2, const float *A, const float *W1, const float *G1
 
 // interact_rows.hip: the row-stationary kernel 256 channels run on
 int gwen_mlp2_rows_f();
-int gwen_mlp2_rows_launch(int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,
+int gwen_mlp2_rows_launch(int F, int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,
                           const float *G2, const int32_t *idx2, const float *b1, const float *W2,
                           const float *b2, const float *res, float *out, int64_t R, int act,
                           const int32_t *rowptr, const int32_t *tile_row, int64_t n_tiles, float *agg,
@@ -498,13 +500,13 @@ extern "C" int gwen_mlp2_supported(int64_t F) {
 }
 
 extern "C" int gwen_mlp2_rows(int64_t F) {
-  return F == 32 ? MCfg<32>::ROWS : F == 64 ? MCfg<64>::ROWS : F == 128 ? MCfg<128>::ROWS
+  return F == 32 ? MCfg<32>::ROWS : F == 64 ? gwen_mlp2_rows_f() : F == 128 ? MCfg<128>::ROWS
        : F == 256 ? gwen_mlp2_rows_f() : GWEN_EINVAL;
 }
 
 extern "C" int64_t gwen_mlp2_workspace_bytes(int64_t F) {
   if (!gwen_mlp2_supported(F)) return GWEN_EINVAL;
-  return F > 128 ? 2 * 2 * F * F * 2 : 0;      // two matrices x (hi, lo) x bf16
+  return F > 128 || F == 64 ? 2 * 2 * F * F * 2 : 0;      // two matrices x (hi, lo) x bf16
 }
 
 extern "C" int64_t gwen_edge_tiles_count(int64_t E, int64_t T) {
@@ -563,10 +565,10 @@ extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, c
     return launch_mode<FF>(m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, \
                            tile_row, n_tiles, agg, mean, workspace, (uint32_t)(ldg1 * 4),       \
                            (uint32_t)(ldg2 * 4), st)
-  GWEN_M(32); GWEN_M(64); GWEN_M(128);
-#undef GWEN_M
-  if (F == 256)
-    return gwen_mlp2_rows_launch(m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, tile_row,
+  if (F == 256 || F == 64)
+    return gwen_mlp2_rows_launch((int)F, m1, m2, A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr, tile_row,
                                  n_tiles, agg, mean, workspace, (uint32_t)(ldg1 * 4), (uint32_t)(ldg2 * 4), st);
+  GWEN_M(32); GWEN_M(128);
+#undef GWEN_M
   return GWEN_EINVAL;
 }

@@ -1,30 +1,35 @@
-// K6 at 256 channels, ROW-STATIONARY -- the same contract as k_mlp2 (interact.hip):
+// K6 at 64 and 256 channels, ROW-STATIONARY -- the same contract as k_mlp2 (interact.hip):
 //
 //     pre[r] = A[r] W1^T + G1[idx1[r]] + G2[idx2[r]] + b1 ;  y[r] = act(pre[r]) W2^T + b2
 //     out[r] = res[r] + y[r] ;  agg[d] = sum_{r : dst(r) = d} y[r]      (rows sorted by d, stored order)
 //
 // At 256 channels the two weight matrices as 3xbf16 hi/lo fragments are 512 KB, the whole register file of a
-// CU, so they cannot stay resident.  k_mlp2 keeps the activations in LDS and lets every wave stream ITS
-// column slice of W from L2, one k-step ahead: per 64-row pass a CU pulls 512 KB of fragments through the
-// vector memory path, each k-step (384 cycles of MFMA per wave) waits for an L2 round trip, and the hidden
-// layer crosses LDS between two barriers (measured: 890 us for 600 000 edges = 0.21 of the bf16 MFMA peak;
+// CU, so they cannot stay resident.  k_mlp2 kept the activations in LDS and let every wave stream ITS
+// column slice of W from L2, one k-step ahead: per 64-row pass a CU pulled 512 KB of fragments through the
+// vector memory path, each k-step (384 cycles of MFMA per wave) waited for an L2 round trip, and the hidden
+// layer crossed LDS between two barriers (measured: 886 us for 600 000 edges = 0.21 of the bf16 MFMA peak;
 // 690 us with the fragment loads removed).  Here the roles are swapped:
-//   * a wave owns 16 ROWS and all 256 columns of them -- its A rows, the first contraction's accumulators
-//     (= the hidden layer) and the second one's live in registers, three sets of 64; a lane holds, of row
+//   * a wave owns 16 ROWS and all F columns of them -- its A rows, the first contraction's accumulators
+//     (= the hidden layer) and the second one's live in registers, three sets of F / 4; a lane holds, of row
 //     lane % 16, the 4 columns 16 j + 4 (lane / 16) .. + 3 of every 16-column tile j;
 //   * the k index of a contraction may be permuted freely as long as both operands agree, so a k-step takes
 //     as "its" 32 channels the two column tiles 2 ks and 2 ks + 1 in exactly that register layout: the B
 //     operand (8 values per lane) is read straight from the lane's registers -- the A rows for the first
 //     contraction, the activated accumulators for the second -- and the hidden layer never touches LDS;
 //     the weight images (k_split_wr) are written in the matching order;
-//   * the weights are the shared operand: one k-step of a matrix is 32 KB of fragments for ALL 16 column
-//     tiles, brought by LDS-DMA (global_load_lds_dwordx4, no registers) into a ring of three slots, two
-//     k-steps ahead, and read by all 8 waves -- 256 KB per 128-row pass and matrix instead of 512 KB per 64;
-//   * one barrier per k-step (it frees the slot the next DMA overwrites); the aggregation goes through a
-//     64-column fp32 tile in LDS four times per pass, summed per target row in stored order by one thread
-//     per (row, 4 columns) as in k_mlp2 -- no atomics, bitwise reproducible.
-// The DMAs are inline asm (hipcc neither counts nor drains them); the waits for them are explicit and count
-// the vector-memory instructions issued since (cdna_hip_programming.md, "Pipelining across barriers").
+//   * the weights are the shared operand.  256 channels: one k-step of a matrix is 32 KB of fragments for ALL 16
+//     column tiles, brought by LDS-DMA (global_load_lds_dwordx4, no registers) into a ring of three slots, two
+//     k-steps ahead, and read by all 8 waves -- 256 KB per 128-row pass and matrix instead of 512 KB per 64 --
+//     with one barrier per k-step (it frees the slot the next DMA overwrites).  64 channels: both matrices'
+//     fragments are 32 KB and stay in LDS for the whole launch: no ring, no per-step barrier, two blocks per CU;
+//   * the aggregation goes through a 64-column fp32 tile in LDS (four times per pass at 256 channels), summed
+//     per target row in stored order by one thread per (row, 4 columns) as in k_mlp2 -- no atomics, bitwise
+//     reproducible, independent of the tiling;
+//   * 64 channels: A rows are read and out rows written in a ROW layout -- 16 lanes on the 256 contiguous bytes
+//     of a row -- and turned into / out of the MFMA layout through the wave's own 16 rows of that LDS tile: the
+//     MFMA layout's natural access, 64-B pieces of 16 different rows per instruction, cost 15 % of the kernel.
+// The ring's DMAs are inline asm (hipcc neither counts nor drains them); the waits for them are explicit and
+// count the vector-memory instructions issued since (cdna_hip_programming.md, "Pipelining across barriers").
 // Register roles rotate: the next pass's A rows are loaded into the hidden layer's registers as the second
 // contraction releases them, and the finished pass's A registers receive the next pass's gathered G2 rows
 // (the first contraction accumulates onto them), so the pass body exists twice with the two sets swapped.
@@ -66,7 +71,16 @@ struct RCfg {
   static constexpr int NW = 8 / RT;                 // waves per block
   static constexpr int ROWS = NW * RT * 16;         // rows per pass: 128
   static constexpr int STEP = NJ * 2 * 1024;        // bytes of W fragments per k-step: (tile, hi/lo) x 1 KB
-  static constexpr int NSLOT = 3;
+  // F <= 64: both matrices' fragments (2 KS steps, 32 KB at F = 64) stay RESIDENT in LDS for the whole launch --
+  // no ring, no per-step waits or barriers, no inline-asm DMA in the loop -- and two blocks share a CU
+  static constexpr bool RESIDENT = F <= 64;
+  static constexpr int NSLOT = RESIDENT ? 2 * KS : 3;
+  // A rows and out rows cross global memory in a ROW layout (16 lanes on 256 contiguous bytes) and are turned
+  // into / out of the MFMA layout through LDS: at 64 channels -15 % (the MFMA layout's natural access is 64-B
+  // pieces of 16 different rows per instruction); at 256 channels (1 KB rows) it measured 690 -> 739 us, off
+  static constexpr bool ROWIO = RESIDENT;
+  static constexpr int GS = KS < 4 ? KS : 4;        // steps of the first contraction that load G1 rows
+  static constexpr int MINW = RESIDENT ? 4 : 2;     // waves per SIMD to compile for
   static constexpr int DPW = STEP / 1024 / NW;      // DMA instructions per wave and k-step
   static constexpr int YC = 64, PY = YC + 4;        // aggregation chunk: columns, LDS pitch (floats)
   static constexpr int NCH = F / YC, JC = YC / 16;
@@ -160,13 +174,13 @@ template <int F, int RT, int M1, int M2, int RES>
 struct Vis {
   static constexpr int of(int si) {
     using C = RCfg<F, RT>;
-    if (si < C::KS) return RT * (((M1 != kNone && si < 4) ? C::NJ / 4 : 0) + (RES == kResOther ? 2 : 0));
+    if (si < C::KS) return RT * (((M1 != kNone && si < C::GS) ? C::NJ / C::GS : 0) + (RES == kResOther ? 2 : 0));
     return RT * (2 + (si == C::KS ? (M1 == kIdx ? 1 : 0) + (M2 == kIdx ? 1 : 0) : 0));
   }
 };
 
 template <int F, int RT, int M1, int M2, bool SEG, int RES>
-__global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
+__global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k_mlp2r(
     const float *__restrict__ A, const char *__restrict__ img, const float *__restrict__ G1,
     const int32_t *__restrict__ idx1, const float *__restrict__ G2, const int32_t *__restrict__ idx2,
     const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ res,
@@ -241,8 +255,10 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
   };
 
   float4_t ra[NR], rb[NR], rc[NR];
-  int32_t i1[RT], i2[RT];                                            // table rows of the CURRENT pass's rows
-  int32_t i1n[RT], i2n[RT];                                          // ... of the next pass's
+  // table rows of the CURRENT pass's rows and of the next pass's.  (The gathered G1 / G2 rows stay in the MFMA
+  // layout's 64-B pieces: read in the row layout with four indices per lane and turned through LDS, the
+  // 64-channel edge kernel measured 99 -> 108 us -- rows of one target share their G2 row anyway.)
+  int32_t i1[RT], i2[RT], i1n[RT], i2n[RT];
 
   Pass cur, nxt;
   span(tile0, cur);
@@ -258,7 +274,15 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
     i1n[rt] = i2n[rt] = 0;
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j) {
-      ra[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + col(j));
+      if constexpr (C::ROWIO) {                                      // A rows: the row layout (see pass_body)
+        int32_t last = (cur.e1 < R ? cur.e1 : R) - 1;
+        last = last < 0 ? 0 : last;
+        int32_t row = cur.w0 + (wave * RT + rt) * 16 + 4 * (j % 4) + g;
+        row = row < last ? row : last;
+        ra[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(A + (int64_t)row * F + (j / 4) * 64 + 4 * mi);
+      } else {
+        ra[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(A + (int64_t)rr * F + col(j));
+      }
       if constexpr (M2 != kNone)
         rb[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(reinterpret_cast<const char *>(G2) +
                                                                  ((uint32_t)i2[rt] * ldb2 + col(j) * 4u));
@@ -266,8 +290,14 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
         rb[rt * C::NJ + j] = float4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
-  dma(0, 0);
-  dma(1, 1);
+  if constexpr (C::RESIDENT) {
+    static_for<2 * C::KS>([&](auto cc) { dma(decltype(cc)::value, decltype(cc)::value); });
+    wait_vm<0>();                                                    // once; the first step's barrier publishes it
+    __syncthreads();
+  } else {
+    dma(0, 0);
+    dma(1, 1);
+  }
 
   using V = Vis<F, RT, M1, M2, RES>;
 
@@ -297,7 +327,29 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
     int32_t rr_next[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) rr_next[rt] = clamp_row(fol, rt);
+    int32_t last_next = (fol.e1 < R ? fol.e1 : R) - 1;
+    last_next = last_next < 0 ? 0 : last_next;
     const int64_t pass_off = (int64_t)cur.w0 * F;
+    // E arrives in the row layout (see the loads in the second contraction's steps): through this wave's own 16
+    // rows of the y tile -- free between two aggregations, touched by no other wave here -- into the MFMA layout
+    auto to_mfma = [&](float4_t (&X)[NR]) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        int gt = g, mt = mi;                                         // opaque: no hoisted LDS addresses
+        asm volatile("" : "+v"(gt), "+v"(mt));
+        float *yown = ytile + (wave * RT + rt) * 16 * C::PY;
+        float *yw = yown + gt * C::PY + 4 * mt;                      // row layout: row 4 k + g, columns 4 (lane % 16)
+        const float *yr = yown + mt * C::PY + 4 * gt;                // MFMA layout: row lane % 16, columns 16 j + 4 g
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) *reinterpret_cast<float4_t *>(yw + 4 * k * C::PY) = X[rt * C::NJ + 4 * c + k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) X[rt * C::NJ + 4 * c + j] = *reinterpret_cast<const float4_t *>(yr + 16 * j);
+        }
+      }
+    };
+    if constexpr (C::ROWIO) to_mfma(E);
 
     static_for<2 * C::KS>([&](auto ss) {
       constexpr int si = decltype(ss)::value;
@@ -305,18 +357,20 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
       constexpr int ks = first ? si : si - C::KS;
       // this step's view of the lane's column offset: opaque, or hipcc keeps 16 loop-invariant offsets per
       // table live across the whole pass loop (and spills them)
-      int gs = g;
-      asm volatile("" : "+v"(gs));
+      int gs = g, ms = mi;
+      asm volatile("" : "+v"(gs), "+v"(ms));
       auto col = [&](int j) { return 16 * j + 4 * gs; };
-      // ---- chunk si has landed (its DMA is two steps old); everything younger may stay in flight ------------
-      if constexpr (si == 0) wait_vm<0>();
-      else if constexpr (si == 1) wait_vm<C::DPW + V::of(0)>();
-      else wait_vm<V::of(si - 2) + C::DPW + V::of(si - 1)>();
-      STAMP(si == 0 ? 0 : 1);
+      if constexpr (!C::RESIDENT) {
+        // ---- chunk si has landed (its DMA is two steps old); everything younger may stay in flight ----------
+        if constexpr (si == 0) wait_vm<0>();
+        else if constexpr (si == 1) wait_vm<C::DPW + V::of(0)>();
+        else wait_vm<V::of(si - 2) + C::DPW + V::of(si - 1)>();
+        STAMP(si == 0 ? 0 : 1);
 #if ABL != 2
-      __syncthreads();                                               // ... for every wave; slot - 1 is free
+        __syncthreads();                                             // ... for every wave; slot - 1 is free
 #endif
-      STAMP(2);
+        STAMP(2);
+      }
       if constexpr (si == C::KS) {
         // the activation: hidden = act(acc + G1 rows + b1), in place; the second accumulators start at b2.
         // BEFORE this step's DMAs: hipcc waits for the G1 rows with its own count, which does not know the
@@ -333,7 +387,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
             rc[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(bl + F + col(j));
           }
       }
-      {
+      if constexpr (!C::RESIDENT) {
         const int into = slot >= 1 ? slot - 1 : C::NSLOT - 1;        // (slot + 2) % 3
 #if ABL != 3 && ABL != 4
         dma((si + 2) % (2 * C::KS), into);
@@ -355,10 +409,10 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         if constexpr (first) {
-          if constexpr (M1 != kNone && si < 4) {
+          if constexpr (M1 != kNone && si < C::GS) {
             const char *p1 = reinterpret_cast<const char *>(G1) + ((uint32_t)i1[rt] * ldb1 + 16u * gs);
 #pragma unroll
-            for (int j = si * (C::NJ / 4); j < (si + 1) * (C::NJ / 4); ++j)
+            for (int j = si * (C::NJ / C::GS); j < (si + 1) * (C::NJ / C::GS); ++j)
               rc[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(p1 + 64 * j);
           }
           if constexpr (RES == kResOther) {                          // E's registers are free: the residual rows
@@ -375,10 +429,21 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
             if constexpr (M1 == kIdx) i1n[rt] = idx1[rr_next[rt]];
             if constexpr (M2 == kIdx) i2n[rt] = idx2[rr_next[rt]];
           }
-          const char *pa = reinterpret_cast<const char *>(A + (int64_t)rr_next[rt] * F) + 16 * gs;
+          // the next pass's A rows in the ROW layout (register 4 c + k: row 4 k + lane / 16, columns 64 c + 4 (lane
+          // % 16) ..+3 -- 16 lanes read 256 contiguous bytes); the pass turns them into the MFMA layout at its top
+          if constexpr (C::ROWIO) {
 #pragma unroll
-          for (int j = 2 * ks; j < 2 * ks + 2; ++j)
-            H[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(pa + 64 * j);
+            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
+              int32_t row = fol.w0 + (wave * RT + rt) * 16 + 4 * (j % 4) + gs;
+              row = row < last_next ? row : last_next;
+              H[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(A + (int64_t)row * F + (j / 4) * 64 + 4 * ms);
+            }
+          } else {
+            const char *pa = reinterpret_cast<const char *>(A + (int64_t)rr_next[rt] * F) + 16 * gs;
+#pragma unroll
+            for (int j = 2 * ks; j < 2 * ks + 2; ++j)
+              H[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(pa + 64 * j);
+          }
         }
       }
       // ---- 16 column tiles x RT row tiles x 3 products; W fragments from the ring, two accumulators a group ----
@@ -418,15 +483,42 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
     // 679 -> 701 us.) --------------------------------------------------------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      int gs = g, ps = prow(rt);
+      int gs = g, ps = mi;
       asm volatile("" : "+v"(gs), "+v"(ps));
-      if (out && prow(rt) < n_rows) {
-        char *po = reinterpret_cast<char *>(out + pass_off) + (uint32_t)(ps * F * 4 + 16 * gs);
+      if constexpr (!C::ROWIO) {
+        if (out && prow(rt) < n_rows) {
+          char *po = reinterpret_cast<char *>(out + pass_off) + (uint32_t)(prow(rt) * F * 4 + 16 * gs) + 0 * ps;
 #pragma unroll
-        for (int j = 0; j < C::NJ; ++j) {
-          float4_t o = rc[rt * C::NJ + j];
-          if constexpr (RES != kResNone) o += E[rt * C::NJ + j];
-          *reinterpret_cast<float4_t *>(po + 64 * j) = o;
+          for (int j = 0; j < C::NJ; ++j) {
+            float4_t o = rc[rt * C::NJ + j];
+            if constexpr (RES != kResNone) o += E[rt * C::NJ + j];
+            *reinterpret_cast<float4_t *>(po + 64 * j) = o;
+          }
+        }
+      } else if (out) {
+        // through the wave's own rows of the y tile into the row layout: 16 lanes store 256 contiguous bytes
+        float *yown = ytile + (wave * RT + rt) * 16 * C::PY;
+        const int wrow = (wave * RT + rt) * 16;
+        float *po = out + pass_off + (int64_t)(wrow + gs) * F + 4 * ps;       // ps: lane % 16 here
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float4_t o = rc[rt * C::NJ + 4 * c + j];
+            if constexpr (RES != kResNone) o += E[rt * C::NJ + 4 * c + j];
+            *reinterpret_cast<float4_t *>(yown + ps * C::PY + 16 * j + 4 * gs) = o;
+          }
+          float4_t v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4_t *>(yown + (4 * k + gs) * C::PY + 4 * ps);
+          if (wrow + 16 <= n_rows) {                                   // the wave's 16 rows all exist: no per-row test
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (wrow + 4 * k + gs < n_rows) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v[k];
+          }
         }
       }
       const char *p2 = reinterpret_cast<const char *>(G2) + ((uint32_t)i2n[rt] * ldb2 + 16u * gs);
@@ -502,7 +594,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64)) void k_mlp2r(
     pass_body(rb, ra);
     if (last_pass) break;
   }
-  wait_vm<0>();                                                      // the DMAs issued past the last chunk used
+  if constexpr (!C::RESIDENT) wait_vm<0>();                          // the DMAs issued past the last chunk used
   STAMP_FLUSH;
 }
 
@@ -526,7 +618,7 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
     GWEN_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
     cus = n < 8 ? 8 : n;
   }
-  int64_t blocks = cus;                                              // one block per CU (130 KB of LDS)
+  int64_t blocks = (int64_t)cus * (C::RESIDENT ? 2 : 1);              // 130 KB of LDS at 256 channels, 68 KB at 64
   if (blocks > tiles) blocks = tiles;
   const int r = !res ? kResNone : (res == A ? kResA : kResOther);
   const char *im = reinterpret_cast<const char *>(img);
@@ -552,19 +644,20 @@ namespace {
 
 }  // namespace
 
-int gwen_mlp2_rows_f() { return RCfg<256, K6R_RT>::ROWS; }
+int gwen_mlp2_rows_f() { return RCfg<256, K6R_RT>::ROWS; }   // the same at every width this kernel takes
 
 // interact.hip's dispatch for F = 256 (pointers validated there); m1 / m2 as interact.hip's kNone / kSelf / kIdx
-int gwen_mlp2_rows_launch(int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,
+int gwen_mlp2_rows_launch(int F, int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,
                           const float *G2, const int32_t *idx2, const float *b1, const float *W2,
                           const float *b2, const float *res, float *out, int64_t R, int act,
                           const int32_t *rowptr, const int32_t *tile_row, int64_t n_tiles, float *agg,
                           int mean, void *workspace, uint32_t ldb1, uint32_t ldb2, hipStream_t st) {
-#define GWEN_MODE(A1, A2)                                                                             \
-  if (m1 == A1 && m2 == A2)                                                                           \
-    return launch_rows<256, A1, A2>(A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr,  \
-                                    tile_row, n_tiles, agg, mean, workspace, ldb1, ldb2, st)
-  GWEN_MODE(kNone, kNone); GWEN_MODE(kSelf, kNone); GWEN_MODE(kIdx, kNone); GWEN_MODE(kIdx, kIdx);
+#define GWEN_MODE(FF, A1, A2)                                                                         \
+  if (F == FF && m1 == A1 && m2 == A2)                                                                \
+    return launch_rows<FF, A1, A2>(A, W1, G1, idx1, G2, idx2, b1, W2, b2, res, out, R, act, rowptr,   \
+                                   tile_row, n_tiles, agg, mean, workspace, ldb1, ldb2, st)
+  GWEN_MODE(256, kNone, kNone); GWEN_MODE(256, kSelf, kNone); GWEN_MODE(256, kIdx, kNone); GWEN_MODE(256, kIdx, kIdx);
+  GWEN_MODE(64, kNone, kNone); GWEN_MODE(64, kSelf, kNone); GWEN_MODE(64, kIdx, kNone); GWEN_MODE(64, kIdx, kIdx);
 #undef GWEN_MODE
   return GWEN_EINVAL;
 }
