@@ -190,7 +190,7 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30):
             "roofline": {"bound": "hbm" if f <= 64 else "mfma", "compulsory_bytes": b_comp,
                          "achieved_GBs": round(b_comp / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                          "frac": round(b_comp / t / 1e9 / HBM_PEAK_GBS, 4),
-                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([f"k_mlp2<{f},"]),
+                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([f"k_mlp2r<{f},", f"k_mlp2<{f},"]),
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
