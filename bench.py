@@ -27,6 +27,9 @@ Extra objects on the JSON line (DESIGN.md "Measurement"):
                    kernel duration / 8 TB/s; traffic = PMC bytes from the committed rocprofv3 passes.
   hbm_leg_64ch  -- the same stack at c2's 64 channels on 16 members (819 MB of activations per layer): the layer
                    kernel where the 3xbf16 matrix work is a quarter of the 256-channel one per byte.
+  edge_mlp_block, edge_mlp_block_8_members -- the InteractionNet edge-MLP + aggregation kernel (K6, the block
+                   BASELINE's north_star names) on the same mesh at the same width, one member and 8 members
+                   batched: us per launch and the compulsory-bytes HBM fraction.
   exact_f32     -- the c2 step with every contraction on the fp32-input MFMA (order "fused_exact").
   cpu_baseline  -- the torch oracle (kind "port": the reference's PyG is not installable) timed on this
                    host's cores, all cores and one thread, rank 0, N = 1 only.
@@ -156,13 +159,16 @@ class Sampler:
         return min(counts.values()) if counts else 0
 
 
-def edge_mlp_side_measurement(mesh, f, dev, launches=30):
+def edge_mlp_side_measurement(mesh, f, dev, launches=30, members=1):
     """K6 (gwen_mlp2_f32: gathers + edge MLP + residual + in-order sum to targets) on the mesh's edges
-    at width f: torch events on the launch stream around `launches` back-to-back launches."""
+    at width f: torch events on the launch stream around `launches` back-to-back launches.  members > 1: the
+    block-diagonal graph of that many members (the c5 driver's per-GPU batch), far beyond the Infinity Cache."""
     from gwen_amd import ops
     from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
     g = interaction_graph(torch.from_numpy(mesh.edge_index).to(dev), mesh.num_nodes, mesh.num_nodes)
-    n, e = mesh.num_nodes, g.num_edges
+    if members > 1:
+        g = g.batched(members)
+    n, e = g.num_dst, g.num_edges
     torch.manual_seed(23)
     net = InteractionNet(f).to(dev)
     x = torch.randn(n, f, device=dev)
@@ -184,13 +190,13 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30):
     t = a.elapsed_time(b) / launches * 1e-3
     b_l2 = 4 * f * (4 * e + n) + 8 * e + 4 * n        # e read, e' written, two gathered rows, agg, indices
     b_comp = 4 * f * (2 * e + 2 * n) + 12 * e + 4 * n  # e, e' once; x, agg once; src/dst/rowptr
-    return {"workload": f"InteractionNet edge kernel (K6), F={f}, same mesh: gathers + 2-layer edge MLP + "
-                        f"residual + in-order sum to targets, one launch", "edges": e,
+    return {"workload": f"InteractionNet edge kernel (K6), F={f}, same mesh x {members} member(s): gathers + 2-layer "
+                        f"edge MLP + residual + in-order sum to targets, one launch", "edges": e,
             "us_per_launch": round(t * 1e6, 1), "edge_updates_per_s": round(e / t),
             "roofline": {"bound": "hbm" if f <= 64 else "mfma", "compulsory_bytes": b_comp,
                          "achieved_GBs": round(b_comp / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                          "frac": round(b_comp / t / 1e9 / HBM_PEAK_GBS, 4),
-                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([f"k_mlp2r<{f},", f"k_mlp2<{f},"]),
+                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([f"k_mlp2r<{f},", f"k_mlp2<{f},"]) if members == 1 else None,
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
@@ -461,6 +467,8 @@ def main():
     # value above stays the reference's own layer (GCNConv) -------------------------------------------
     if single and not args.no_edge_mlp and h in (32, 64, 128, 256):
         line["edge_mlp_block"] = edge_mlp_side_measurement(mesh, h, dev)
+        # ... and on 8 members at once (2.9 GB of compulsory traffic at 64 channels: nothing stays in a cache)
+        line["edge_mlp_block_8_members"] = edge_mlp_side_measurement(mesh, h, dev, launches=10, members=8)
 
     # ---- CPU baseline: the torch oracle on this host's cores (rank 0, N = 1 only) ----------------
     if single and not args.no_cpu_baseline:

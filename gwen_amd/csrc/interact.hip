@@ -506,7 +506,7 @@ extern "C" int gwen_mlp2_rows(int64_t F) {
 
 extern "C" int64_t gwen_mlp2_workspace_bytes(int64_t F) {
   if (!gwen_mlp2_supported(F)) return GWEN_EINVAL;
-  return F > 128 || F == 64 ? 2 * 2 * F * F * 2 : 0;      // two matrices x (hi, lo) x bf16
+  return F > 128 ? 2 * 2 * F * F * 2 : 0;      // two matrices x (hi, lo) x bf16
 }
 
 extern "C" int64_t gwen_edge_tiles_count(int64_t E, int64_t T) {

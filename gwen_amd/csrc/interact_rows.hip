@@ -149,15 +149,17 @@ __device__ inline float4_t activate(float4_t v, int act) {
 
 // W [F,F] fp32 (row = output column) -> the k-step-major fragment image: k-step ks, column tile jo, (hi, lo),
 // lane l = (i = l % 16, g = l / 16): the 8 values W[16 jo + i][32 ks + 4 g .. + 3], W[16 jo + i][32 ks + 16 + 4 g .. + 3]
+// (blockIdx.y: 0 = W1 -> the first KS chunks of the image, 1 = W2 -> the next KS: one launch for both)
 template <int F>
-__global__ __launch_bounds__(64) void k_split_wr(const float *__restrict__ W, bf16x8 *__restrict__ img) {
+__global__ __launch_bounds__(64) void k_split_wr(const float *__restrict__ W1, const float *__restrict__ W2,
+                                                 bf16x8 *__restrict__ img) {
   using C = RCfg<F>;
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
   const int jo = blockIdx.x / C::KS, ks = blockIdx.x % C::KS;
-  const float *wp = W + (int64_t)(jo * 16 + i) * F + 32 * ks + 4 * g;
+  const float *wp = (blockIdx.y ? W2 : W1) + (int64_t)(jo * 16 + i) * F + 32 * ks + 4 * g;
   bf16x8 hi, lo;
   split8(*reinterpret_cast<const float4_t *>(wp), *reinterpret_cast<const float4_t *>(wp + 16), hi, lo);
-  bf16x8 *dst = img + (int64_t)ks * (C::STEP / 16) + (jo * 2) * 64 + lane;
+  bf16x8 *dst = img + (int64_t)(blockIdx.y * C::KS + ks) * (C::STEP / 16) + (jo * 2) * 64 + lane;
   dst[0] = hi;
   dst[64] = lo;
 }
@@ -181,7 +183,8 @@ struct Vis {
 
 template <int F, int RT, int M1, int M2, bool SEG, int RES>
 __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k_mlp2r(
-    const float *__restrict__ A, const char *__restrict__ img, const float *__restrict__ G1,
+    const float *__restrict__ A, const char *__restrict__ img, const float *__restrict__ W1f,
+    const float *__restrict__ W2f, const float *__restrict__ G1,
     const int32_t *__restrict__ idx1, const float *__restrict__ G2, const int32_t *__restrict__ idx2,
     const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ res,
     float *__restrict__ out, int32_t R, int act, const int32_t *__restrict__ rowptr,
@@ -291,8 +294,17 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
     }
   }
   if constexpr (C::RESIDENT) {
-    static_for<2 * C::KS>([&](auto cc) { dma(decltype(cc)::value, decltype(cc)::value); });
-    wait_vm<0>();                                                    // once; the first step's barrier publishes it
+    // every block splits the two fp32 matrices into its own LDS image itself (32 KB of L2-resident reads): no
+    // pre-split pass, no workspace traffic -- two tiny launches in front of a 100 us kernel cost 4-5 % of it
+    for (int p = wave; p < 2 * C::KS * C::NJ; p += C::NW) {          // fragment pairs (matrix, ks, jo)
+      const int m = p / (C::KS * C::NJ), ks = (p / C::NJ) % C::KS, jo = p % C::NJ;
+      const float *wp = (m ? W2f : W1f) + (int64_t)(jo * 16 + mi) * F + 32 * ks + 4 * g;
+      bf16x8 hi, lo;
+      split8(*reinterpret_cast<const float4_t *>(wp), *reinterpret_cast<const float4_t *>(wp + 16), hi, lo);
+      char *dst = lds + (m * C::KS + ks) * C::STEP + (jo * 2) * 1024 + lane * 16;
+      *reinterpret_cast<bf16x8 *>(dst) = hi;
+      *reinterpret_cast<bf16x8 *>(dst + 1024) = lo;
+    }
     __syncthreads();
   } else {
     dma(0, 0);
@@ -607,9 +619,10 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
   using C = RCfg<F, K6R_RT>;
   const bool seg = agg != nullptr;
   bf16x8 *img = reinterpret_cast<bf16x8 *>(workspace);               // W1's k-steps, then W2's
-  k_split_wr<F><<<C::NJ * C::KS, 64, 0, st>>>(W1, img);
-  k_split_wr<F><<<C::NJ * C::KS, 64, 0, st>>>(W2, img + (int64_t)C::KS * (C::STEP / 16));
-  GWEN_LAUNCH_CHECK();
+  if constexpr (!C::RESIDENT) {                                      // 64 channels: split inside the kernel
+    k_split_wr<F><<<dim3(C::NJ * C::KS, 2), 64, 0, st>>>(W1, W2, img);
+    GWEN_LAUNCH_CHECK();
+  }
   const int64_t tiles = seg ? n_tiles : (R + C::ROWS - 1) / C::ROWS;
   static int cus = 0;
   if (cus == 0) {
@@ -624,7 +637,7 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
   const char *im = reinterpret_cast<const char *>(img);
 #define GWEN_R(SEGV, RV)                                                                              \
   k_mlp2r<F, K6R_RT, M1, M2, SEGV, RV><<<(unsigned)blocks, C::NW * 64, 0, st>>>(                              \
-      A, im, G1, idx1, G2, idx2, b1, b2, res, out, (int32_t)R, act, SEGV ? rowptr : nullptr,          \
+      A, im, W1, W2, G1, idx1, G2, idx2, b1, b2, res, out, (int32_t)R, act, SEGV ? rowptr : nullptr,  \
       SEGV ? tile_row : nullptr, (int32_t)tiles, SEGV ? agg : nullptr, SEGV ? mean : 0, ldb1, ldb2)
   if (seg) {
     if (r == kResNone) GWEN_R(true, kResNone); else if (r == kResA) GWEN_R(true, kResA); else GWEN_R(true, kResOther);

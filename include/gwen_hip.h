@@ -418,8 +418,8 @@ int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_la
  *   rowptr[N_agg] == R) and tile_row [n_tiles+1] comes from gwen_edge_tiles; every target row is
  *   summed by one block in stored order (no atomics; rows without entries get 0).
  *   The contractions use the 3xbf16 split (see gwen_gcn_layer_f32, exact = 0).
- *   workspace: gwen_mlp2_workspace_bytes(F) bytes, 16-byte aligned (GWEN_ENOSPACE if smaller): F = 64 and 256
- *   run on the row-stationary kernel, which takes its weights as pre-split bf16 fragment images.
+ *   workspace: gwen_mlp2_workspace_bytes(F) bytes, 16-byte aligned (GWEN_ENOSPACE if smaller): only F = 256
+ *   needs one -- its weights are streamed from pre-split bf16 fragment images (F = 64 splits them in-kernel).
  *
  * gwen_edge_tiles: row-aligned tiling of a CSR's entries.  tile c owns the target rows whose first
  *   entry lies in [cT, (c+1)T); n_tiles = gwen_edge_tiles_count(E, T) = max(1, ceil(E/T)); T <= 128.
@@ -432,7 +432,7 @@ int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_la
 #define GWEN_ACT_SILU 2
 int gwen_mlp2_supported(int64_t F);          /* F in {32, 64, 128, 256} */
 int gwen_mlp2_rows(int64_t F);                /* rows one pass of the kernel takes at width F (128 at F = 64 and 256, else 64) */
-int64_t gwen_mlp2_workspace_bytes(int64_t F); /* F = 64, 256: room for the pre-split weight images; else 0 */
+int64_t gwen_mlp2_workspace_bytes(int64_t F); /* F = 256: room for the pre-split weight images; else 0 */
 int64_t gwen_edge_tiles_count(int64_t E, int64_t T);
 int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int64_t T, int32_t *tile_row,
                     int32_t *dst, gwen_stream_t stream);
