@@ -80,6 +80,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-edge-mlp", action="store_true",
                    help="skip the side measurement of the InteractionNet edge-MLP kernel (K6)")
+    p.add_argument("--edge-mlp-members", type=int, default=8,
+                   help="members of the batched edge-MLP side measurement (0: skip -- the PMC passes do, so that a "
+                        "kernel name averages over one launch shape)")
     p.add_argument("--no-hbm-leg", action="store_true")
     p.add_argument("--no-exact", action="store_true")
     p.add_argument("--hbm-members", type=int, default=4)
@@ -468,7 +471,9 @@ def main():
     if single and not args.no_edge_mlp and h in (32, 64, 128, 256):
         line["edge_mlp_block"] = edge_mlp_side_measurement(mesh, h, dev)
         # ... and on 8 members at once (2.9 GB of compulsory traffic at 64 channels: nothing stays in a cache)
-        line["edge_mlp_block_8_members"] = edge_mlp_side_measurement(mesh, h, dev, launches=10, members=8)
+        if args.edge_mlp_members > 1:
+            line[f"edge_mlp_block_{args.edge_mlp_members}_members"] = edge_mlp_side_measurement(
+                mesh, h, dev, launches=10, members=args.edge_mlp_members)
 
     # ---- CPU baseline: the torch oracle on this host's cores (rank 0, N = 1 only) ----------------
     if single and not args.no_cpu_baseline:
