@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch, gwen_amd
 from gwen_amd import _lib
 from gwen_amd.interaction import InteractionNet, interaction_graph
-F = 256
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mesh = gwen_amd.geodesic_mesh(100, reorder="hilbert")
 ei = torch.from_numpy(mesh.edge_index).cuda()
 keep = ei[0] != ei[1]
@@ -14,7 +14,7 @@ g = interaction_graph(ei[:, keep], mesh.num_nodes, mesh.num_nodes)
 net = InteractionNet(F).cuda().eval()
 x = torch.randn(mesh.num_nodes, F, device="cuda"); e = torch.randn(g.num_edges, F, device="cuda")
 L = _lib.lib()
-st = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
+st = torch.zeros(512 * 8 * 8, dtype=torch.int64, device="cuda")
 L.gwen_k6r_set_stamps.argtypes = [C.c_void_p]
 from gwen_amd import ops, interaction as I
 with torch.no_grad():
@@ -29,7 +29,7 @@ with torch.no_grad():
     assert L.gwen_k6r_set_stamps(C.c_void_p(st.data_ptr())) == 0
     run()
     torch.cuda.synchronize()
-t = st.view(256, 8, 8).double().cpu()
+t = st.view(512, 8, 8).double().cpu(); t = t[t.sum((1, 2)) > 0]
 tot = t.sum(-1)
 names = ["step-0 drain", "DMA waits", "step barriers", "step bodies", "activation step", "agg: y tile + barriers", "agg: stores + G2", "agg: sums"]
 print(f"per-wave stamped cycles: mean total {tot.mean():.0f} (min {tot.min():.0f}, max {tot.max():.0f})")
