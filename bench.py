@@ -61,6 +61,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--prewarm-ms", type=float, default=100.0,
+                   help="untimed steady-state run-in before the W warm-up steps (the first ms after an idle gap "
+                        "run at ramping clocks)")
     p.add_argument("--nu", type=int, default=100, help="mesh frequency: N = 10 nu^2 + 2")
     p.add_argument("--channels", type=int, default=64)
     p.add_argument("--hidden", type=int, default=64)
@@ -118,6 +121,21 @@ def compulsory_bytes(kind, n, e, fin, fout, members=1):
     if kind == "propagate":
         return 8 * members * n * fin + idx
     return 4 * members * n * (fin + fout) + idx + 4 * fin * fout
+
+
+PREWARM_S = 0.1
+
+
+def prewarm(fn, seconds=None):
+    """Keep the GPU busy with the work about to be measured for `seconds` (untimed): after an idle gap -- tensors
+    made on the host, a finished leg -- the first ~5-40 ms of launches run 8-20 % slow (clock ramp; measured with
+    tools/experiments/warm_ramp.py).  Every measurement below starts from the steady state."""
+    seconds = PREWARM_S if seconds is None else seconds
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
 
 
 def pmc_traffic(tag_prefixes):
@@ -181,9 +199,7 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30, members=1):
         p = ops.linear(x, wn, bn, exact=False)
         run = lambda: mlp2(ef, we, net.edge_mlp[2].weight, net.edge_mlp[2].bias, g1=p[:, :f], idx1=g.src,   # noqa: E731
                            g2=p[:, f:2 * f], idx2=g.dst, res=ef, graph=g)
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
+        prewarm(run)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(launches):
@@ -217,9 +233,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
     plan = ga.StackForward(layers, graph)
     x = torch.stack([torch.randn(n, f, generator=torch.Generator().manual_seed(123 + k)) for k in range(m)]).to(dev)
     out = plan.run(x)
-    for _ in range(2):
-        plan.run(x, out=out)
-    torch.cuda.synchronize()
+    prewarm(lambda: plan.run(x, out=out))
     samp = Sampler(ga, 2 * nl)
     steps = max(args.hbm_steps, (MIN_SAMPLES + nl - 1) // nl)
     t0 = time.perf_counter()
@@ -332,6 +346,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    prewarm(step, args.prewarm_ms / 1e3)
     for _ in range(args.warmup):
         step()
     if world > 1:   # RCCL sets its rings/channels up on the first collective: keep that out of the timing
@@ -417,7 +432,7 @@ def main():
         pass64 = round(m_local * e / (tot_ / cnt_))
     line = {
         "metric": "mesh edges/s (message+aggregate)", "value": value, "unit": "edges/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"c2: geodesic mesh nu={args.nu} N={n} E={e}, GNNModel forward "
@@ -443,9 +458,7 @@ def main():
         set_order("fused_exact")
         plan_x = gwen_amd.StackForward(model.stack(), graph)
         out_x = plan_x.run(x)
-        for _ in range(5):
-            plan_x.run(x, out=out_x)
-        torch.cuda.synchronize()
+        prewarm(lambda: plan_x.run(x, out=out_x))
         k_x = max(20, min(args.steps, 100))
         tx = time.perf_counter()
         for _ in range(k_x):

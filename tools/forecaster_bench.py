@@ -21,9 +21,11 @@ xm = torch.randn(M, mesh.faces.shape[0], C, device=dev)
 
 
 def timed(fn, k=10, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+    t0 = time.perf_counter()             # >= 0.1 s of the same work first: the clocks ramp for tens of ms after idling
+    while time.perf_counter() - t0 < 0.1:
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(k):
         fn()

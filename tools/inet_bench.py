@@ -9,9 +9,12 @@ from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
 
 
 def timed(fn, iters):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()             # 0.1 s of the same work first: the clocks ramp for tens of ms after idling
+    while time.perf_counter() - t0 < 0.1:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
