@@ -118,6 +118,8 @@ SIGNATURES = {
                               _vp, _i64, _int, _vp, C.c_size_t, _vp]),
     "gwen_mlp2_workspace_bytes": (_i64, [_i64]),
     "gwen_mlp2_rows": (_int, [_i64]),
+    "gwen_masked_l1_workspace_floats": (_i64, []),
+    "gwen_masked_l1_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
 
 

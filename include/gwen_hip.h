@@ -444,6 +444,20 @@ int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_
                   int64_t n_tiles, float *agg, int64_t N_agg, int mean, void *workspace,
                   size_t workspace_bytes, gwen_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Masked L1 loss, value and gradient in one pass -- the reference's training objective
+ * (/root/reference/src/gwen/models_gnn.py:261-265: F.l1_loss(output[mask], target[mask]); backward :372):
+ *     loss[0] = sum_{m, r : mask[r], c} |out[m,r,c] - target[m,r,c]| / (picked * C * members)
+ *     grad[m,r,c] = sign(out - target) * mask[r] / (picked * C * members)      (grad may be NULL)
+ * out, target, grad: fp32 [members, N, C] contiguous, C % 4 == 0, 16-byte aligned; mask: one byte per row [N]
+ * (non-zero = selected); picked = number of selected rows (0 => NaN, as torch).  Three launches, sums in a
+ * fixed order (bitwise reproducible).  workspace: gwen_masked_l1_workspace_floats() floats.
+ * ------------------------------------------------------------------------------------------- */
+int64_t gwen_masked_l1_workspace_floats(void);
+int gwen_masked_l1_f32(const float *out, const float *target, const uint8_t *mask, int64_t members, int64_t N,
+                       int64_t C, float *grad, float *loss, float *workspace, int64_t workspace_floats,
+                       gwen_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -618,3 +618,36 @@ def test_precision_switch_train_and_eval_agree(ga):
         assert errs["fp32"] <= 2e-6 and errs["fp32"] <= errs["3xbf16"]
     with pytest.raises(ValueError):
         model.set_precision("bf16")
+
+
+@pytest.mark.parametrize("members,n,c", [(1, 1002, 64), (3, 777, 8), (1, 100002, 64), (2, 5, 4)])
+def test_masked_l1_fused_vs_reference_formula(ga, members, n, c):
+    """loss_func on the GPU (gwen_masked_l1_f32: value + gradient in one pass) against the reference's own
+    expression l1_loss(output[mask], target[mask]) (models_gnn.py:261-265) and its autograd, in fp64."""
+    g = torch.Generator().manual_seed(SEED + n + c)
+    shape = (n, c) if members == 1 else (members, n, c)
+    o = torch.randn(*shape, generator=g)
+    t = torch.randn(*shape, generator=g)
+    t.view(-1)[::7] = o.view(-1)[::7]                                # exact zeros of the difference: sign(0) = 0
+    mask = torch.rand(n, generator=g) < 0.5
+    od = o.to(DEV).requires_grad_(True)
+    loss = ga.loss_func(od, t.to(DEV), mask.to(DEV))
+    loss.backward()
+    o64 = o.double().requires_grad_(True)
+    sel = (o64[mask], t.double()[mask]) if members == 1 else (o64[:, mask], t.double()[:, mask])
+    want = torch.nn.functional.l1_loss(*sel)
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-6 * abs(float(want))
+    assert torch.allclose(od.grad.cpu().double(), o64.grad, rtol=1e-6, atol=0)
+    again = ga.loss_func(od.detach(), t.to(DEV), mask.to(DEV))       # fixed-order sums: bitwise reproducible
+    assert torch.equal(again, loss.detach())
+    half = ga.loss_func(od, t.to(DEV), mask.to(DEV)) * 0.5           # an upstream factor reaches the gradient
+    od.grad = None
+    half.backward()
+    assert torch.allclose(od.grad.cpu().double(), 0.5 * o64.grad, rtol=1e-6, atol=0)
+
+
+def test_masked_l1_empty_mask_is_nan_like_torch(ga):
+    o = torch.randn(64, 8, device=DEV)
+    none = torch.zeros(64, dtype=torch.bool, device=DEV)
+    assert torch.isnan(ga.loss_func(o, torch.zeros_like(o), none))
