@@ -79,6 +79,8 @@ struct RCfg {
   // into / out of the MFMA layout through LDS: at 64 channels -15 % (the MFMA layout's natural access is 64-B
   // pieces of 16 different rows per instruction); at 256 channels (1 KB rows) it measured 690 -> 739 us, off
   static constexpr bool ROWIO = RESIDENT;
+  // ... the out rows alone, one 16-B piece at a time (no registers to spare), do pay at 256 channels: 653 -> 622 us
+  static constexpr bool ROWST = true;
   static constexpr int GS = KS < 4 ? KS : 4;        // steps of the first contraction that load G1 rows
   static constexpr int MINW = RESIDENT ? 4 : 2;     // waves per SIMD to compile for
   static constexpr int DPW = STEP / 1024 / NW;      // DMA instructions per wave and k-step
@@ -497,7 +499,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
     for (int rt = 0; rt < RT; ++rt) {
       int gs = g, ps = mi;
       asm volatile("" : "+v"(gs), "+v"(ps));
-      if constexpr (!C::ROWIO) {
+      if constexpr (!C::ROWST) {
         if (out && prow(rt) < n_rows) {
           char *po = reinterpret_cast<char *>(out + pass_off) + (uint32_t)(prow(rt) * F * 4 + 16 * gs) + 0 * ps;
 #pragma unroll
@@ -520,16 +522,25 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
             if constexpr (RES != kResNone) o += E[rt * C::NJ + 4 * c + j];
             *reinterpret_cast<float4_t *>(yown + ps * C::PY + 16 * j + 4 * gs) = o;
           }
-          float4_t v[4];
+          if constexpr (C::ROWIO) {
+            float4_t v[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4_t *>(yown + (4 * k + gs) * C::PY + 4 * ps);
-          if (wrow + 16 <= n_rows) {                                   // the wave's 16 rows all exist: no per-row test
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4_t *>(yown + (4 * k + gs) * C::PY + 4 * ps);
+            if (wrow + 16 <= n_rows) {                                 // the wave's 16 rows all exist: no per-row test
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v[k];
-          } else {
+              for (int k = 0; k < 4; ++k) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v[k];
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (wrow + 4 * k + gs < n_rows) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v[k];
+              for (int k = 0; k < 4; ++k)
+                if (wrow + 4 * k + gs < n_rows) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v[k];
+            }
+          } else {                                                     // 256 channels: one piece at a time
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float4_t v = *reinterpret_cast<const float4_t *>(yown + (4 * k + gs) * C::PY + 4 * ps);
+              if (wrow + 4 * k + gs < n_rows) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v;
+              asm volatile("" ::: "memory");
+            }
           }
         }
       }
