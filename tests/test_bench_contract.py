@@ -1,0 +1,59 @@
+"""bench.py: the byte models behind its roofline objects (CPU) and the JSON line's contract (GPU, tiny run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_byte_models_match_the_survey_formulas():
+    import bench
+    n, e = 100_002, 600_000                                       # c2: nu = 100 mesh, directed edges without loops
+    # SURVEY 8(d) for a gather at width F: F * 4 * (E' + N) with E' = E + N stored entries, + indices
+    assert bench.algorithmic_bytes("propagate", n, e, 64, 64) == 4 * 64 * (e + 2 * n) + 8 * e + 8 * n
+    # the c2 dominant kernel (K5 64 -> 64 -> 32, stored 32 wide): the figures DESIGN.md section 5 quotes
+    assert bench.algorithmic_bytes("chain", n, e, 64, 32) == 197_600_784
+    assert bench.compulsory_bytes("chain", n, e, 64, 32) == 44_408_984
+    # compulsory = every input, output, index and weight byte once; members scale the activations only
+    one = bench.compulsory_bytes("wide", n, e, 256, 256, 1)
+    four = bench.compulsory_bytes("wide", n, e, 256, 256, 4)
+    assert four - one == 3 * 4 * n * (256 + 256)
+    assert bench.compulsory_bytes("linear", n, e, 256, 768) == 4 * n * (256 + 768) + 4 * 256 * 768
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.MIN_SAMPLES >= 10
+
+
+def test_default_flags_are_the_contract(monkeypatch):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.steps > 0, a.warmup > 0) == (1, True, True)
+    assert a.nu == 100 and a.channels == 64 and a.hidden == 64    # BASELINE.json configs[1]
+    assert a.prewarm_ms > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_a_tiny_run(hip_lib):
+    """One JSON line with the fields the driver parses, `roofline` (frac <= 1, >= 10 samples) and `cpu_baseline`."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--no-hbm-leg", "--no-exact",
+           "--cpu-seconds", "1", "--edge-mlp-members", "0", "--prewarm-ms", "20"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("l2", "hbm", "mfma") and 0.0 < r["frac"] <= 1.0 and r["samples"] >= 10
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["gpu_vs_oracle_rel_err"] <= 1e-4
+    assert d["value"] > 1e9 and abs(d["value"] - 6 * 600_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
