@@ -2,8 +2,12 @@
 """bench.py -- GWEN GCNConv-stack hot path on MI355X: mesh edges/s (message+aggregate).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU: the reference's
+                                                            mp.spawn, /root/reference/src/gwen/train_gnn.py:144-152)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --workload c5 [--gpus N]               (BASELINE configs[4]: 4 members per GPU, 4-step
+                                                            grid->mesh->grid rollout, members/s incl. the one gather)
 
 Headline workload (BASELINE.json configs[1], "c2"): synthetic ICON-CH1-scale geodesic mesh, nu = 100 ->
 N = 100 002 nodes, E = 600 000 directed edges; GNNModel(channels 64 -> hidden 64 -> 64), fp32 storage,
@@ -40,6 +44,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,6 +58,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: "~2.5 PF dense" bf16 MFMA
 L2_GATHER_GBS = 17800.0        # same guide, "Indexed rows": rows served by the XCD's L2, 16.8-18.8 TB/s chip-wide
 MIN_SAMPLES = 10
 
@@ -59,8 +66,19 @@ MIN_SAMPLES = 10
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=None, help="default: 200 (c2), 10 (c5)")
+    p.add_argument("--warmup", type=int, default=None, help="default: 20 (c2), 2 (c5)")
+    p.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                   help="c2: BASELINE configs[1], GNNModel forward on the nu=100 mesh, edges/s (the headline); "
+                        "c5: BASELINE configs[4], InteractionNet grid->mesh->grid forecaster, 4 members per GPU, "
+                        "4-step autoregressive rollout + ONE all-gather, members/s")
+    p.add_argument("--launch-dry-run", action="store_true",
+                   help="with --gpus N > 1 and no WORLD_SIZE in the environment: print the N child command lines "
+                        "and their rank environments as one JSON object and exit without starting them")
+    p.add_argument("--rollout-steps", type=int, default=4, help="c5: autoregressive steps per rollout")
+    p.add_argument("--c5-channels", type=int, default=256, help="c5: grid channels = hidden width")
+    p.add_argument("--c5-blocks", type=int, default=4, help="c5: mesh->mesh processor blocks")
+    p.add_argument("--c5-members-per-gpu", type=int, default=4)
     p.add_argument("--prewarm-ms", type=float, default=100.0,
                    help="untimed steady-state run-in before the W warm-up steps (the first ms after an idle gap "
                         "run at ramping clocks)")
@@ -94,7 +112,59 @@ def parse():
     p.add_argument("--hbm-layers", type=int, default=4)
     p.add_argument("--hbm-steps", type=int, default=12)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU baseline leg")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.steps is None:
+        a.steps = 200 if a.workload == "c2" else 10
+    if a.warmup is None:
+        a.warmup = 20 if a.workload == "c2" else 2
+    return a
+
+
+# ---- self-launch: `python bench.py --gpus N` starts its own ranks ------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_plan(n_ranks, argv, port=None, base_env=None):
+    """The N child processes `python bench.py --gpus N` starts when no launcher set WORLD_SIZE: one per GPU, each
+    a FRESH interpreter running this file with the parent's flags and the rank environment torch.distributed.run
+    would give it (the reference starts its ranks itself too: /root/reference/src/gwen/train_gnn.py:144-152,
+    rendezvous by MASTER_ADDR / MASTER_PORT, models_gnn.py:321-322).  Returns [(argv, env-additions)]."""
+    port = port or _free_port()
+    child_argv = [a for a in argv if a != "--launch-dry-run"]
+    plan = []
+    for r in range(n_ranks):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+               "HSA_ENABLE_IPC_MODE_LEGACY": (base_env or os.environ).get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        plan.append(([sys.executable, os.path.abspath(__file__)] + child_argv, env))
+    return plan
+
+
+def run_plan(plan, poll_s=0.2):
+    """Start every child, wait for all; the first non-zero exit code ends the others (exact PIDs) and is returned.
+    The parent never touches the GPU, so nothing that has initialised HIP is ever re-executed."""
+    procs = []
+    for argv, env in plan:
+        procs.append(subprocess.Popen(argv, env={**os.environ, **env}))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(poll_s)
+        for p_ in list(live):
+            code = p_.poll()
+            if code is None:
+                continue
+            live.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                for q_ in live:
+                    q_.terminate()
+    return rc
 
 
 def algorithmic_bytes(kind, n, e, fin, fout):
@@ -270,13 +340,24 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
     }
 
 
-def main():
-    args = parse()
+def init_ranks(args):
+    """(world, rank, dev) of this process; starts the ranks itself when nobody else did."""
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # BEFORE anything touches the GPU: this parent only starts N fresh interpreters and waits for them
+        plan = launch_plan(args.gpus, sys.argv[1:])
+        if args.launch_dry_run:
+            print(json.dumps({"launcher": "bench.py self-launch (one fresh process per GPU)", "n_ranks": args.gpus,
+                              "children": [{"argv": a, "env": e} for a, e in plan]}))
+            raise SystemExit(0)
+        raise SystemExit(run_plan(plan))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_dry_run:
+        print(json.dumps({"launcher": "none needed", "n_ranks": world, "children": []}))
+        raise SystemExit(0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -284,6 +365,199 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return world, rank, dev
+
+
+def timed_allgather_object(ag0, ag1, final, world, dev):
+    ag_ms = torch.tensor([ag0.elapsed_time(ag1)], dtype=torch.float64, device=dev)
+    seen = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(ag_ms, op=dist.ReduceOp.MAX)
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    per_rank = final.numel() * 4
+    return {"ms": round(float(ag_ms.item()), 4), "bytes_per_rank": per_rank,
+            "busbw_GBs": round(per_rank * (world - 1) / (float(ag_ms.item()) * 1e-3) / 1e9, 2),
+            "ranks_seen": int(seen.item()), "world_size": dist.get_world_size(),
+            "backend": dist.get_backend(),
+            "note": "one all_gather_into_tensor of the final states, inside the timed region; "
+                    "busbw = bytes received per rank / time (each rank receives (world-1) shards)"}
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            return next(ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        return "unknown CPU"
+
+
+def cpu_thread_sweep(fn, budget_s, counts=None):
+    """Median time of fn() at each thread count (1, 8, 16, 32, 64, all -- those the host has); returns
+    (best_threads, best_median, {threads: (median, reps)}, last result).  The stated baseline is the BEST
+    configuration found, not the widest one (torch's index_add_ does not scale with threads)."""
+    all_cores = torch.get_num_threads()
+    counts = counts or sorted({c_ for c_ in (1, 8, 16, 32, 64, all_cores) if c_ <= all_cores})
+    per_leg = budget_s / max(len(counts), 1)
+    res, last = {}, None
+    for th in counts:
+        torch.set_num_threads(th)
+        with torch.no_grad():
+            tw = time.perf_counter(); last = fn(); one = time.perf_counter() - tw       # warm-up
+            reps = max(1, min(20, int(per_leg / max(one, 1e-3))))
+            ts = []
+            for _ in range(reps):
+                tw = time.perf_counter(); last = fn(); ts.append(time.perf_counter() - tw)
+        res[th] = (sorted(ts)[len(ts) // 2], reps)
+    torch.set_num_threads(all_cores)
+    best = min(res, key=lambda k_: res[k_][0])
+    return best, res[best][0], res, last
+
+
+def run_c5(args, world, rank, dev):
+    """BASELINE configs[4]: the build-defined InteractionNet grid->mesh->grid forecaster (gwen_amd/forecaster.py;
+    the reference has no such model -- SURVEY section 0 -- its only part kept is the eval's shape: compute locally,
+    ONE all-gather at the end, /root/reference/src/gwen/models_gnn.py:471).  One STEP = one R-step autoregressive
+    rollout of every local member (all of them through one launch set per step, captured once and replayed) + the
+    single gather of the final states.  value = members * K / t  [members per second, whole job]."""
+    import gwen_amd
+    from gwen_amd import ensemble
+    from gwen_amd.forecaster import InteractionForecaster, ensemble_forecast
+
+    ch, nb, r_steps, m_local = args.c5_channels, args.c5_blocks, args.rollout_steps, args.c5_members_per_gpu
+    members = m_local * world
+    lo, hi = ensemble.member_range(members, rank, world)
+    mesh = gwen_amd.geodesic_mesh(args.nu, reorder=None if args.reorder == "none" else args.reorder)
+    n_grid, n_mesh = mesh.faces.shape[0], mesh.num_nodes
+    torch.manual_seed(23)
+    model = InteractionForecaster(ch, ch, nb).to(dev).eval()
+    graphs = model.prepare(mesh, dev)
+    x = torch.stack([torch.randn(n_grid, ch, generator=torch.Generator().manual_seed(23 + m))
+                     for m in range(lo, hi)]).to(dev)
+    cache = {}                                  # the captured step lives here: timed calls only replay
+
+    def step():
+        return ensemble_forecast(model, graphs, x, r_steps, members, graphed=True, batched=True, step_cache=cache)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    out = step()                                # capture + RCCL channel set-up, outside the timed region
+    # steady-state run-in on local work only (a time-bounded loop must not contain a collective)
+    prewarm(lambda: ensemble_forecast(model, graphs, x, 1, members, graphed=True, batched=True, step_cache=cache,
+                                      gather=False), args.prewarm_ms / 1e3)
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    assert out.shape[0] == members and torch.isfinite(out).all()
+
+    allgather = None
+    if world > 1:               # the collective by itself (outside the timed region; the timed steps contain it)
+        local = out[lo:hi].contiguous()
+        ag0, ag1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ag0.record()
+        ensemble.gather_members(local, members)
+        ag1.record()
+        torch.cuda.synchronize()
+        allgather = timed_allgather_object(ag0, ag1, local, world, dev)
+
+    edges = graphs.g2m.num_edges + nb * graphs.mesh.num_edges + graphs.m2g.num_edges
+    line = {
+        "metric": "ensemble members/s (autoregressive rollout incl. the final all-gather)",
+        "value": members * args.steps / elapsed, "unit": "members/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c5: InteractionNet forecaster (build-defined; the reference has no grid/mesh model), "
+                               f"geodesic mesh nu={args.nu}: grid {n_grid} cells -> mesh {n_mesh} vertices -> grid, "
+                               f"{ch} channels, {nb} processor blocks, {r_steps}-step autoregressive rollout, "
+                               f"{m_local} members/GPU batched through one launch set per step",
+                   "grid_nodes": n_grid, "mesh_nodes": n_mesh, "edge_updates_per_model_step": edges,
+                   "channels": ch, "processor_blocks": nb, "rollout_steps": r_steps, "members": members,
+                   "node_order": args.reorder, "contraction": "3xbf16-split (fp32 storage and accumulation)",
+                   "hip_graph": True,
+                   "parallelism": f"ensemble members sharded 1 rank = {m_local} members; one all-gather at end"},
+        "edge_updates_per_s": members * r_steps * edges * args.steps / elapsed,
+    }
+    if allgather is not None:
+        line["allgather"] = allgather
+    if rank == 0 and world == 1:
+        # dominant kernel of the step: K6's edge kernel on the mesh->mesh blocks, by itself on the same batch
+        side = edge_mlp_side_measurement(mesh, ch, dev, launches=10, members=m_local)
+        t_k6 = side["us_per_launch"] * 1e-6
+        e_b = side["edges"]
+        if ch <= 64:
+            comp = side["roofline"]["compulsory_bytes"]
+            line["roofline"] = {"bound": "hbm", "kernel": f"k_mlp2r<{ch}> (K6 edge kernel) x {m_local} members",
+                                "achieved": round(comp / t_k6 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(comp / t_k6 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                "compulsory_bytes_per_launch": comp, "avg_launch_us": side["us_per_launch"]}
+        else:
+            flops = 12 * ch * ch * e_b             # two F x F contractions per edge, 3 bf16 terms each, 2 flop/MAC
+            line["roofline"] = {"bound": "mfma", "kernel": f"K6 edge kernel at {ch} channels x {m_local} members",
+                                "achieved": round(flops / t_k6 / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(flops / t_k6 / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                "traffic": None, "flops_per_launch_bf16_issued": flops,
+                                "avg_launch_us": side["us_per_launch"],
+                                "note": "bf16 MFMA flops ISSUED (3 terms per fp32-class product); fp32-equivalent "
+                                        "work is a third of it"}
+        if not args.no_cpu_baseline:
+            from oracle import interaction_oracle as IO
+            line["cpu_baseline"] = c5_cpu_baseline(IO, model, mesh, graphs, x, out, args, members, elapsed)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def c5_cpu_baseline(IO, model, mesh, graphs, x, out, args, members, elapsed):
+    """The plain-torch restatement of the forecaster (oracle/interaction_oracle.py) on this host: ONE model step of
+    ONE member (a bounded sample: a full 4-member x 4-step rollout at 256 channels is minutes of CPU work)."""
+    import numpy as np
+    from gwen_amd.forecaster import edge_features
+    from gwen_amd.g2m import grid_mesh_edges
+    g2m, m2g = grid_mesh_edges(mesh)
+    cell = mesh.pos[mesh.faces].mean(axis=1)
+    cell /= np.linalg.norm(cell, axis=1, keepdims=True)
+    feats = [torch.from_numpy(v) for v in (edge_features(cell, mesh.pos, g2m),
+                                           edge_features(mesh.pos, mesh.pos, mesh.edge_index),
+                                           edge_features(mesh.pos, cell, m2g))]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    pos = torch.from_numpy(mesh.pos.astype(np.float32))
+    eis = [torch.from_numpy(v) for v in (g2m, mesh.edge_index, m2g)]
+    xc = x[0].cpu()
+    all_c = torch.get_num_threads()
+    with torch.no_grad():
+        best_t, med, sweep, y1 = cpu_thread_sweep(
+            lambda: IO.forecaster_step(sd, xc, pos, *eis, *feats, args.c5_blocks), args.cpu_seconds,
+            counts=sorted({c_ for c_ in (1, 8, 32, all_c) if c_ <= all_c}))
+    # one device step of the same member against it
+    with torch.no_grad():
+        got = model(x[0], graphs).cpu()
+    err = float((got - y1).abs().max() / y1.abs().max())
+    per_member = med * args.rollout_steps
+    return {"value": 1.0 / per_member, "unit": "members/s", "cores": best_t, "kind": "port",
+            "sample": f"{sweep[best_t][1]} single forecaster steps of one member (median {med*1e3:.0f} ms), "
+                      f"x {args.rollout_steps} steps per rollout; torch {torch.__version__} CPU, {best_t} thread(s), best of "
+                      f"a sweep on {cpu_model_name()}; oracle/interaction_oracle.py (build-defined model: parity unpinned)",
+            "thread_sweep": {str(th): {"median_ms": round(v[0] * 1e3, 1), "passes": v[1]} for th, v in sorted(sweep.items())},
+            "gpu_vs_oracle_rel_err_one_step": err}
+
+
+def main():
+    args = parse()
+    world, rank, dev = init_ranks(args)
+    if args.workload == "c5":
+        return run_c5(args, world, rank, dev)
 
     import gwen_amd
     from gwen_amd import ensemble
@@ -377,19 +651,7 @@ def main():
     elapsed = float(elapsed.item())
     assert gathered.shape[0] == members and torch.isfinite(gathered).all()
 
-    allgather = None
-    if world > 1:
-        ag_ms = torch.tensor([ag0.elapsed_time(ag1)], dtype=torch.float64, device=dev)
-        seen = torch.ones(1, dtype=torch.int64, device=dev)
-        dist.all_reduce(ag_ms, op=dist.ReduceOp.MAX)
-        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
-        per_rank = final.numel() * 4
-        allgather = {"ms": round(float(ag_ms.item()), 4), "bytes_per_rank": per_rank,
-                     "busbw_GBs": round(per_rank * (world - 1) / (float(ag_ms.item()) * 1e-3) / 1e9, 2),
-                     "ranks_seen": int(seen.item()), "world_size": dist.get_world_size(),
-                     "backend": dist.get_backend(),
-                     "note": "one all_gather_into_tensor of the final states, inside the timed region; "
-                             "busbw = bytes received per rank / time (each rank receives (world-1) shards)"}
+    allgather = timed_allgather_object(ag0, ag1, final, world, dev) if world > 1 else None
 
     # ---- more instrumented steps (outside the timed region) until every kernel has MIN_SAMPLES ------
     while samp.min_samples() < MIN_SAMPLES:
@@ -495,36 +757,19 @@ def main():
         ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
         xc = (x if x.dim() == 2 else x[0]).cpu()
         eic = torch.from_numpy(mesh.edge_index)
-        cpu_model = "unknown CPU"
-        try:
-            with open("/proc/cpuinfo") as fh:
-                cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
-        except (OSError, StopIteration):
-            pass
-
-        def cpu_leg(threads):
-            torch.set_num_threads(threads)
-            with torch.no_grad():
-                tw = time.perf_counter(); yc_ = ref(xc, eic); one = time.perf_counter() - tw   # warm-up
-                reps = max(1, min(20, int(args.cpu_seconds / max(one, 1e-3))))
-                ts = []
-                for _ in range(reps):
-                    tw = time.perf_counter(); yc_ = ref(xc, eic); ts.append(time.perf_counter() - tw)
-            return sorted(ts)[len(ts) // 2], reps, yc_
-
+        cpu_model = cpu_model_name()
         all_cores = torch.get_num_threads()
-        med, reps, yc = cpu_leg(all_cores)
-        med1, reps1, _ = cpu_leg(1)
-        torch.set_num_threads(all_cores)
+        with torch.no_grad():
+            best_t, med, sweep, yc = cpu_thread_sweep(lambda: ref(xc, eic), 2.0 * args.cpu_seconds)
         got = (out if out.dim() == 2 else out[0]).cpu()
         err = float((got - yc).abs().max() / yc.abs().max())
         line["cpu_baseline"] = {
-            "value": layers * e / med, "unit": "edges/s", "cores": all_cores, "kind": "port",
-            "sample": f"{reps} full GNNModel.forward passes of the same c2 workload (1 member), median "
-                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU ({all_cores} threads on {cpu_model}), "
-                      f"oracle/gcn_oracle.py",
-            "one_thread": {"value": layers * e / med1, "cores": 1,
-                           "sample": f"{reps1} passes, median {med1*1e3:.1f} ms, torch.set_num_threads(1)"},
+            "value": layers * e / med, "unit": "edges/s", "cores": best_t, "kind": "port",
+            "sample": f"{sweep[best_t][1]} full GNNModel.forward passes of the same c2 workload (1 member), median "
+                      f"{med*1e3:.1f} ms, torch {torch.__version__} CPU, {best_t} thread(s) -- the best of a sweep -- "
+                      f"on {cpu_model} ({all_cores} hardware threads), oracle/gcn_oracle.py",
+            "thread_sweep": {str(th): {"edges_per_s": round(layers * e / v[0]), "median_ms": round(v[0] * 1e3, 1),
+                                       "passes": v[1]} for th, v in sorted(sweep.items())},
             "gpu_vs_oracle_rel_err": err,
         }
     if rank == 0:

@@ -13,7 +13,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgwen_hip.so")
+# GWEN_HIP_LIB: an experimental variant build (gwen_amd/build.py::build_variant) instead of the product library --
+# for tools/experiments only; tests and bench.py run with it unset.
+LIB_PATH = os.environ.get("GWEN_HIP_LIB") or os.path.join(_HERE, "libgwen_hip.so")
 
 _lib = None
 _lock = threading.Lock()

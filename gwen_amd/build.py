@@ -68,5 +68,44 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, sources=None, verbose: bool = False) -> str:
+    """An EXPERIMENTAL build beside the product library: ``gwen_amd/variants/libgwen_hip.<name>.so`` with extra
+    ``-D`` flags on the listed sources (default: all).  Select it with ``GWEN_HIP_LIB=<path>`` (gwen_amd/_lib.py).
+    The product library and its stamp are never touched, so an ablated or diagnostic build ("results are wrong
+    by construction") can not leak into tests or bench.py."""
+    build()                                              # the unchanged objects come from the product build
+    vdir = os.path.join(HERE, "variants")
+    odir = os.path.join(vdir, name + ".o")
+    os.makedirs(odir, exist_ok=True)
+    hipcc = _hipcc()
+    changed = list(sources) if sources else list(SOURCES)
+    procs, objs = [], []
+    for src in SOURCES:
+        if src in changed:
+            obj = os.path.join(odir, src.replace(".hip", ".o"))
+            cmd = [hipcc, *FLAGS, *defines, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        else:
+            obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src} ({' '.join(defines)}):\n{out.decode()}")
+    lib = os.path.join(vdir, f"libgwen_hip.{name}.so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:       # python -m gwen_amd.build --variant NAME [--src a.hip,b.hip] -DX=1 ...
+        i = sys.argv.index("--variant")
+        srcs = sys.argv[sys.argv.index("--src") + 1].split(",") if "--src" in sys.argv else None
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv if a.startswith("-D")], srcs, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -39,6 +39,15 @@
 #ifndef WEAVE_VALU
 #define WEAVE_VALU 2
 #endif
+#ifndef K8_ROLES      // experiment: the two waves of a SIMD take the step's two halves in opposite order
+#define K8_ROLES 0
+#endif
+#ifndef K8_PRIO       // experiment: s_setprio around the MFMA half
+#define K8_PRIO 0
+#endif
+#ifndef K8_NT         // experiment: 1 = non-temporal output stores
+#define K8_NT 0
+#endif
 
 namespace {
 
@@ -300,6 +309,38 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     }
   };
 
+  // the same, one pass after the other with half a row's entries in flight (what the register budget at
+  // Fin = 256 leaves when nothing else of the step is interleaved: K8_ROLES)
+  auto aggregate_lean = [&](int sb, int ab, int eb) {
+    const char *ent = lds + kOffEnt + eb * kEntBytes;
+    const char *stg = lds + kOffStage + sb * kStageBytes + mi * 16;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int lr = 4 * NW * p + 4 * wave + mh;
+      const u32x4 l4 = *reinterpret_cast<const u32x4 *>(ent + kRows * 32 + lr * 16);
+      float4_t a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const float4_t w4 = *reinterpret_cast<const float4_t *>(ent + lr * 32 + 16 * hf);
+        float4_t vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t pair = l4[2 * hf + (u >> 1)];
+          const uint32_t lid = (u & 1) ? (pair >> 16) : (pair & 0xffffu);
+          vv[u] = *reinterpret_cast<const float4_t *>(stg + lid * (kFC * 4));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          a4 = __builtin_elementwise_fma(float4_t{w4[u], w4[u], w4[u], w4[u]}, vv[u], a4);
+      }
+      bf16x4 h4, q4;
+      split4(a4, h4, q4);
+      char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
+      *reinterpret_cast<bf16x4 *>(a) = h4;
+      *reinterpret_cast<bf16x4 *>(a + kAImg) = q4;
+    }
+  };
+
   f32x4 d[CT][NTT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -345,7 +386,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   for (int s0 = 0; s0 <= D; ++s0) issue(tile_of(s0 / NC), s0 % NC, s0 % NSTG, (s0 / NC) % 3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  aggregate(0, 0, 0);
+  if constexpr (K8_ROLES != 0 && !DENSE && D == 1) aggregate_lean(0, 0, 0);
+  else aggregate(0, 0, 0);
 
   // ---- steady state: interval s = i NC + c ---------------------------------------------------------------
   //   [scalar loads of the row ids of chunk s+D+1]      (their latency sits behind the wait and the barrier)
@@ -454,6 +496,83 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         afrag[0] = *reinterpret_cast<const bf16x8 *>(ap);
         afrag[1] = *reinterpret_cast<const bf16x8 *>(ap + kAImg);
       }
+      if constexpr (K8_ROLES != 0 && !DENSE && D == 1) {
+        // ---- ROLES: every DMA of chunk s+2 first, then the step's two halves -- X = aggregate(s+1) (LDS reads,
+        // VALU) and Y = mfma(s) (matrix pipe) -- in OPPOSITE order on the two waves of a SIMD (waves w, w + NW/2),
+        // so that one wave's matrix work runs beside the other's vector work instead of both weaving the same
+        // mixture in lockstep between the same two barriers.
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          int32_t r0 = r[4 * q], r1 = r[4 * q + 1], r2 = r[4 * q + 2], r3 = r[4 * q + 3];
+          asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));
+          if (r0 >= 0) {
+            int32_t row = r0;
+            row = mh == 1 ? r1 : row;
+            row = mh == 2 ? r2 : row;
+            row = mh == 3 ? r3 : row;
+            const uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
+            glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
+          }
+        }
+        if (c2 == 0 && wave < 3) {
+          const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t2 * (kRows * 32) + wave * 1024
+                                     : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
+          glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
+        }
+        auto half_y = [&]() {
+          if (c == 0 && spread_stores) {
+#pragma unroll
+            for (int ti = 0; ti < NTT; ++ti) {
+              float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                const int j = CT * jw + ct;
+                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
+                             *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
+                if (relu) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
+                }
+                if (K8_NT) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
+                else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
+                d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
+          }
+          if (K8_PRIO) __builtin_amdgcn_s_setprio(K8_PRIO);
+          gwen_static_for<NU>([&](auto uu) {
+            constexpr int u = decltype(uu)::value;
+            constexpr int ti = u >> 1, k2 = u & 1, ks = 2 * c + k2;
+            const bf16x8 ahi = afrag[0], alo = afrag[1];
+            if constexpr (u + 1 < NU) {
+              constexpr int tn = (u + 1) >> 1, kn = (u + 1) & 1;
+              const char *ap = abase + (((tt0 + tn * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + kn * 64;
+              afrag[0] = *reinterpret_cast<const bf16x8 *>(ap);
+              afrag[1] = *reinterpret_cast<const bf16x8 *>(ap + kAImg);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], alo, d[ct][ti], 0, 0, 0);
+              d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ct][ks], ahi, d[ct][ti], 0, 0, 0);
+              d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], ahi, d[ct][ti], 0, 0, 0);
+            }
+          });
+          if (K8_PRIO) __builtin_amdgcn_s_setprio(0);
+        };
+        auto half_x = [&]() { aggregate_lean(sb1, ab1, eb1); };
+        if (wave < NW / 2) {
+          half_x();
+          __builtin_amdgcn_sched_barrier(0);
+          half_y();
+        } else {
+          half_y();
+          __builtin_amdgcn_sched_barrier(0);
+          half_x();
+        }
+        young = 0;
+        sb = sb + 1 == NSTG ? 0 : sb + 1;
+        return;
+      }
       // ---- the regions --------------------------------------------------------------------------------------
       gwen_static_for<NU>([&](auto uu) {
         constexpr int u = decltype(uu)::value;
@@ -502,7 +621,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
                   for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
                 }
-                *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
+                if (K8_NT) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
+                else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
                 d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
               }
               n_ops += CT;

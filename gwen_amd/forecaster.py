@@ -148,7 +148,7 @@ class InteractionForecaster(nn.Module):
 
 def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
                       n_steps: int, num_members: int, group=None, graphed: bool = True,
-                      batched: bool = True, step_cache: dict = None) -> Tensor:
+                      batched: bool = True, step_cache: dict = None, gather: bool = True) -> Tensor:
     """BASELINE config c5: this rank's members ``[members_local, N_grid, C]`` are rolled out ``n_steps``
     steps (independent members, replicated graph and weights), then every rank's final states are gathered
     ONCE (``ensemble.gather_members``: RCCL all-gather over xGMI under the "nccl" backend).  Returns
@@ -159,6 +159,7 @@ def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
     ``batched=False``: one member after the other (the same arithmetic; kept for comparison).
     ``step_cache``: a dict the captured step lives in between calls (capture costs one eager step plus the
     capture itself; the static embeddings inside it are those of the weights at capture time).
+    ``gather=False`` returns this rank's final states ``[members_local, N_grid, C]`` without the collective.
     ``model`` needs ``_static(graphs)`` and ``_step(x, graphs, static)`` (InteractionForecaster)."""
     from . import ensemble
     m_local = x_members.size(0)
@@ -196,6 +197,8 @@ def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
                     cur = step(cur).clone() if step is not None else model._step(cur, graphs, static)
                 finals.append(cur)
             local = torch.stack(finals)
+    if not gather:
+        return local
     return ensemble.gather_members(local, num_members, group)
 
 

@@ -7,7 +7,9 @@ The reference recomputes ``gcn_norm`` inside each of the six ``GCNConv`` calls o
 tensor object (weak reference + in-place version counter) and, for tensors not seen before, on their
 *content* (a 128-bit device-side checksum): each NeighborLoader batch of the reference's loops
 (models_gnn.py:351-360) is a new tensor object, usually with the same edges -- a content hit -- and a
-relabelled batch has different bytes, so a stale CSR can never be used.
+relabelled batch has different bytes and a different key (the checksum is a 128-bit non-cryptographic sum:
+collision probability ~2^-128 for non-adversarial inputs).  The device is part of the key: equal edge lists
+on two GPUs of one process get a prepared graph each.
 """
 from __future__ import annotations
 
@@ -319,6 +321,8 @@ def content_key(t: Tensor) -> Tuple[int, int]:
     read-back (a stream synchronisation -- the reference's loops synchronise per batch anyway:
     ``.to(device)`` of a pageable tensor at models_gnn.py:358-360, ``loss.item()`` at :447)."""
     t = t.contiguous()
+    if t.data_ptr() % 8:           # the kernel reads 8-byte words: a view at an odd element offset (w[1:]) is copied
+        t = t.clone()
     dev = t.device
     L = _lib.lib()
     ws = torch.empty(int(L.gwen_checksum_workspace_bytes()), dtype=torch.uint8, device=dev)
@@ -375,8 +379,9 @@ class GraphCache:
             del self._by_id[id(edge_index)]
         # unknown (or modified) tensor: by content
         self._check(edge_index, num_nodes)
-        key = (tuple(edge_index.shape), opts, content_key(edge_index),
-               None if edge_weight is None else content_key(edge_weight.detach().to(torch.float32)))
+        key = (str(edge_index.device), tuple(edge_index.shape), opts, content_key(edge_index),
+               None if edge_weight is None else
+               (str(edge_weight.device), content_key(edge_weight.detach().to(torch.float32))))
         g = self._by_content.get(key)
         if g is not None:
             self._by_content.move_to_end(key)

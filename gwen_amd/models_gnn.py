@@ -106,7 +106,7 @@ class _MaskedL1(torch.autograd.Function):
         from . import _lib
         from .graph import _ptr, _stream
         o, t = output.contiguous(), target.contiguous()
-        m = (mask if mask.dtype == torch.bool else mask != 0).contiguous()
+        m = mask.contiguous()                            # bool [N] (loss_func sends nothing else here)
         n, c = o.size(-2), o.size(-1)
         members = o.numel() // (n * c) if n * c else 0
         dev = o.device
@@ -118,12 +118,13 @@ class _MaskedL1(torch.autograd.Function):
             rc = _lib.lib().gwen_masked_l1_f32(_ptr(o), _ptr(t), _ptr(m.view(torch.uint8)), members, n, c, _ptr(grad),
                                                _ptr(loss), _ptr(ws), nws, _stream(dev))
         _lib.check(rc, "gwen_masked_l1_f32")
-        ctx.grad = grad
+        ctx.save_for_backward(*([grad] if grad is not None else []))
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        return (None if ctx.grad is None else ctx.grad * g), None, None
+        saved = ctx.saved_tensors
+        return (saved[0] * g if saved else None), None, None
 
 
 def loss_func(output: Tensor, target: Tensor, target_mask: Tensor) -> Tensor:
@@ -131,11 +132,15 @@ def loss_func(output: Tensor, target: Tensor, target_mask: Tensor) -> Tensor:
     selects.  The reference writes it with boolean indexing, ``l1_loss(output[mask], target[mask])``, which on
     a device costs a nonzero() + sort + two gathers and a host synchronisation per step (~100 us of the c2
     training step); the same mean as a masked sum needs neither.  Only the summation order differs.
-    fp32 tensors on the GPU (channels a multiple of 4, target without a gradient) take ONE fused pass that yields
-    the value and the gradient (gwen_masked_l1_f32: 3 launches instead of ~14); anything else the tensor ops."""
+    BOOL masks (what the reference's dataset produces, utils.py:205) take that path: fp32 tensors on the GPU
+    (channels a multiple of 4, target without a gradient) in ONE fused pass that yields the value and the gradient
+    (gwen_masked_l1_f32: 3 launches instead of ~14), other bool-masked inputs as tensor ops.  Any other mask --
+    an integer INDEX tensor selects (and may repeat) rows -- is the reference's own expression."""
+    if output.dim() < 2 or output.shape != target.shape or target_mask.dtype != torch.bool \
+            or target_mask.dim() != 1 or target_mask.numel() != output.size(-2):
+        return torch.nn.functional.l1_loss(output[target_mask], target[target_mask])
     if (output.is_cuda and output.dtype == torch.float32 and target.dtype == torch.float32 and not target.requires_grad
-            and output.dim() >= 2 and output.shape == target.shape and output.size(-1) % 4 == 0
-            and target_mask.dim() == 1 and target_mask.numel() == output.size(-2)):
+            and output.size(-1) % 4 == 0):
         return _MaskedL1.apply(output, target, target_mask)
     m = target_mask.to(output.dtype).unsqueeze(-1)                  # [N, 1] (broadcasts over a members axis)
     picked = m.sum() * output.size(-1) * (output.numel() // (output.size(-1) * output.size(-2)))

@@ -57,3 +57,65 @@ def test_bench_line_contract_on_a_tiny_run(hip_lib):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["gpu_vs_oracle_rel_err"] <= 1e-4
     assert d["value"] > 1e9 and abs(d["value"] - 6 * 600_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_self_launch_plan_dry_run():
+    """`python bench.py --gpus N` without a launcher starts its own N ranks (the reference's mp.spawn,
+    /root/reference/src/gwen/train_gnn.py:144-152); --launch-dry-run prints the plan and touches no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+                          "--launch-dry-run"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    kids = plan["children"]
+    assert plan["n_ranks"] == 4 and len(kids) == 4
+    assert [k["env"]["RANK"] for k in kids] == ["0", "1", "2", "3"]
+    assert [k["env"]["LOCAL_RANK"] for k in kids] == ["0", "1", "2", "3"]
+    assert {k["env"]["WORLD_SIZE"] for k in kids} == {"4"} and {k["env"]["MASTER_ADDR"] for k in kids} == {"127.0.0.1"}
+    assert len({k["env"]["MASTER_PORT"] for k in kids}) == 1 and {k["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] for k in kids} == {"0"}
+    for k in kids:
+        assert k["argv"][1].endswith("bench.py") and "--launch-dry-run" not in k["argv"]
+        assert k["argv"][2:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    # under a launcher (WORLD_SIZE set) nothing is started
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["children"] == []
+
+
+def test_self_launch_runs_children_and_propagates_failure():
+    import bench
+    ok = [([sys.executable, "-c", "import os; assert os.environ['WORLD_SIZE'] == '3'"], {"RANK": str(r), "WORLD_SIZE": "3"})
+          for r in range(3)]
+    assert bench.run_plan(ok, poll_s=0.05) == 0
+    # rank 1 fails with code 7: the launcher returns it and ends the rank that would run for a minute
+    bad = [([sys.executable, "-c", "import os, sys, time; r = int(os.environ['RANK']); "
+                                   "time.sleep(60) if r == 0 else sys.exit(7 if r == 1 else 0)"], {"RANK": str(r)})
+           for r in range(3)]
+    import time
+    t0 = time.perf_counter()
+    assert bench.run_plan(bad, poll_s=0.05) == 7
+    assert time.perf_counter() - t0 < 30
+
+
+def test_c5_workload_defaults(monkeypatch):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "c5"])
+    a = bench.parse()
+    # BASELINE configs[4]: 256 channels, 4-step rollout, 32 members over 8 GPUs = 4 per GPU
+    assert (a.c5_channels, a.rollout_steps, a.c5_members_per_gpu, a.c5_blocks) == (256, 4, 4, 4)
+    assert a.steps == 10 and a.warmup == 2
+
+
+@pytest.mark.gpu
+def test_c5_bench_line_on_a_small_run(hip_lib):
+    """--workload c5 at 64 channels: members/s line with the roofline of K6 and the oracle-checked CPU baseline."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--c5-channels", "64", "--steps", "2",
+           "--warmup", "1", "--cpu-seconds", "2", "--prewarm-ms", "20"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["unit"] == "members/s" and d["n_gpus"] == 1 and d["config"]["members"] == 4
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
+    assert d["cpu_baseline"]["gpu_vs_oracle_rel_err_one_step"] <= 1e-4

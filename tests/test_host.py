@@ -247,3 +247,21 @@ def test_loss_func_is_the_reference_masked_l1():
     assert abs(float(gwen_amd.loss_func(o3, t3, m)) - float(torch.nn.functional.l1_loss(o3[:, m], t3[:, m]))) <= 1e-6
     none = torch.zeros(50, dtype=torch.bool)
     assert torch.isnan(gwen_amd.loss_func(o, t, none)) and torch.isnan(torch.nn.functional.l1_loss(o[none], t[none]))
+
+
+def test_loss_func_index_mask_is_the_reference_expression():
+    """An integer INDEX mask selects (and may repeat) rows in the reference's ``output[target_mask]``
+    (models_gnn.py:261-265); only bool masks take the masked-sum path."""
+    torch.manual_seed(4)
+    o = torch.randn(20, 8, requires_grad=True)
+    t = torch.randn(20, 8)
+    idx = torch.tensor([3, 3, 7, 19, 0])                       # repeats count twice in the reference
+    a = gwen_amd.loss_func(o, t, idx)
+    b = torch.nn.functional.l1_loss(o[idx], t[idx])
+    assert float(a) == float(b)
+    ga, = torch.autograd.grad(a, o)
+    gb, = torch.autograd.grad(b, o)
+    assert torch.equal(ga, gb)
+    # a 0/1 integer vector of length N is an index tensor too (rows 0 and 1), not a row selector
+    z = torch.zeros(20, dtype=torch.long); z[5] = 1
+    assert float(gwen_amd.loss_func(o, t, z)) == float(torch.nn.functional.l1_loss(o[z], t[z]))
