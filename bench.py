@@ -87,9 +87,9 @@ def parse():
     p.add_argument("--hidden", type=int, default=64)
     p.add_argument("--members-per-gpu", type=int, default=1)
     p.add_argument("--reorder", default="hilbert", choices=["none", "morton", "hilbert"])
-    p.add_argument("--order", default="auto", choices=["auto", "unfused", "fused_exact"],
-                   help="auto: fused kernels, 3xbf16 contraction; fused_exact: fp32-input MFMA; "
-                        "unfused: K3 + K2 per layer")
+    p.add_argument("--order", default="auto", choices=["auto", "bf16x3", "unfused", "fused_exact"],
+                   help="auto: fused kernels, bf16x6 contraction (fp32-class, the library default); bf16x3: the same "
+                        "kernels on the faster two-image split; fused_exact: fp32-input MFMA; unfused: K3 + K2 per layer")
     p.add_argument("--event-stride", type=int, default=40,
                    help="record per-kernel hipEvents on every n-th timed step (each pair of records "
                         "opens a ~10 us gap on the stream, so instrumenting every step would slow the "
@@ -289,8 +289,9 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30, members=1):
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
-def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's per-GPU load"):
-    """BASELINE c3's processor stack at c5's per-GPU member count: the regime where HBM bounds the path."""
+def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's per-GPU load", order="auto"):
+    """BASELINE c3's processor stack at c5's per-GPU member count: the regime where HBM bounds the path.
+    ``order``: "auto" = the library's default contraction (bf16x6), "auto_x3" = the bf16x3 split."""
     n, e = mesh.num_nodes, mesh.num_edges
     f, m, nl = f or args.hbm_channels, m or args.hbm_members, args.hbm_layers
     torch.manual_seed(23)
@@ -299,7 +300,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
         conv = ga.GCNConv(f, f).to(dev)
         with torch.no_grad():
             conv.bias.normal_(0.0, 0.1)
-        layers.append((conv.lin.weight.detach(), conv.bias.detach(), True, "auto"))
+        layers.append((conv.lin.weight.detach(), conv.bias.detach(), True, order))
     plan = ga.StackForward(layers, graph)
     x = torch.stack([torch.randn(n, f, generator=torch.Generator().manual_seed(123 + k)) for k in range(m)]).to(dev)
     out = plan.run(x)
@@ -326,6 +327,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
         "workload": f"{what}: {nl} chained GCN layers {f}->{f} + ReLU, {m} members, "
                     f"nu={args.nu} N={n} E={e}; {ws_mib:.0f} MiB in+out per layer (Infinity Cache: 256 MiB)",
         "members": m, "channels": f, "layers": nl, "steps": steps,
+        "contraction": "bf16x6 (library default, fp32-class)" if order == "auto" else "bf16x3 (precision \"3xbf16\")",
         "ms_per_step": round(dt * 1e3, 4),
         "edges_per_s": round(m * nl * e / dt),
         "roofline": {"bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}] x {m} members",
@@ -585,6 +587,8 @@ def main():
                 elif which == "fused_exact":
                     mod.order = "fused_exact" if gwen_amd.ops.layer_supported(mod.in_channels, mod.out_channels) else \
                         ("aggregate_first" if mod.in_channels < mod.out_channels else "transform_first")
+                elif which == "bf16x3":
+                    mod.order = "auto_x3"
                 else:
                     mod.order = "auto"
     set_order(args.order)
@@ -702,9 +706,12 @@ def main():
                                f"{'/'.join(str(min(a, b)) for a, b in widths)} gathered), {m_local} member/GPU",
                    "nodes": n, "edges": e, "channels": c, "hidden": h, "layers": layers,
                    "members": members, "node_order": args.reorder, "kernel_order": args.order,
-                   "contraction": {"auto": "3xbf16-split (fp32 storage and accumulation; see exact_f32)",
+                   "contraction": {"auto": "bf16x6 split: three bf16 images per operand, six MFMA terms, fp32 "
+                                           "accumulation -- fp32-class (see gpu_vs_oracle_rel_err; siblings: "
+                                           "bf16x3, exact_f32)",
+                                   "bf16x3": "bf16x3 split: two bf16 images per operand, three MFMA terms",
                                    "fused_exact": "fp32-input MFMA (exact fp32 products)",
-                                   "unfused": "3xbf16-split in K3"}[args.order],
+                                   "unfused": "bf16x6 split in K3"}[args.order],
                    "hip_graph": bool(args.graph),
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
         "members_per_s": members * args.steps / elapsed,
@@ -715,9 +722,9 @@ def main():
         line["allgather"] = allgather
 
     single = rank == 0 and world == 1
-    # ---- exact-fp32 sibling of the headline (outside the timed region) --------------------------------
-    if single and not args.no_exact and args.order == "auto":
-        set_order("fused_exact")
+    # ---- siblings of the headline on the other contractions (outside the timed region) ----------------------
+    def sibling(which, text):
+        set_order(which)
         plan_x = gwen_amd.StackForward(model.stack(), graph)
         out_x = plan_x.run(x)
         prewarm(lambda: plan_x.run(x, out=out_x))
@@ -727,18 +734,28 @@ def main():
             plan_x.run(x, out=out_x)
         torch.cuda.synchronize()
         dtx = (time.perf_counter() - tx) / k_x
-        line["exact_f32"] = {"ms_per_step": round(dtx * 1e3, 5), "edges_per_s": round(members * layers * e / dtx),
-                             "contraction": "fp32-input MFMA (v_mfma_f32_16x16x4_f32), order fused_exact",
-                             "steps": k_x,
-                             "max_rel_diff_vs_3xbf16": float((out_x - out).abs().max() / out_x.abs().max())}
-        set_order("auto")
+        set_order(args.order)
+        return {"ms_per_step": round(dtx * 1e3, 5), "edges_per_s": round(members * layers * e / dtx),
+                "contraction": text, "steps": k_x,
+                "max_rel_diff_vs_headline": float((out_x - out).abs().max() / out_x.abs().max())}
+
+    if single and not args.no_exact and args.order == "auto":
+        line["exact_f32"] = sibling("fused_exact", "fp32-input MFMA (v_mfma_f32_16x16x4_f32), order fused_exact")
+        line["bf16x3"] = sibling("bf16x3", "two bf16 images per operand, three MFMA terms (precision \"3xbf16\"): "
+                                           "7e-6 relative on this model, inside the 1e-4 contract")
 
     # ---- HBM-bound leg ----------------------------------------------------------------------------------
     if single and not args.no_hbm_leg:
-        line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev)
-        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache
+        # 256 channels: K8 holds W's images in registers, which three images (bf16x6) exceed -- under the default
+        # precision this width runs on K4; the tile-staged kernel is the bf16x3 tier.  Both are measured.
+        line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x3")
+        line["hbm_leg"]["default_precision_bf16x6"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto")
+        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache: K8 on both splits
         line["hbm_leg_64ch"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
-                                       what="c2's width beyond the Infinity Cache")
+                                       what="c2's width beyond the Infinity Cache", order="auto")
+        line["hbm_leg_64ch"]["bf16x3"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels,
+                                                 m=args.hbm_members_narrow,
+                                                 what="c2's width beyond the Infinity Cache", order="auto_x3")
 
     # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline

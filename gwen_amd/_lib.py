@@ -27,7 +27,8 @@ _vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 class LayerDesc(C.Structure):
     """gwen_layer_desc (include/gwen_hip.h)."""
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("fin", C.c_int32), ("fout", C.c_int32),
-                ("relu", C.c_int32), ("order", C.c_int32), ("packed", C.c_void_p)]
+                ("relu", C.c_int32), ("order", C.c_int32), ("packed", C.c_void_p),
+                ("contract", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LaunchInfo(C.Structure):
@@ -44,8 +45,11 @@ class GraphDesc(C.Structure):
 
 
 ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
+CONTRACT_BF16X3, CONTRACT_F32, CONTRACT_BF16X6 = 0, 1, 2          # GWEN_CONTRACT_* (include/gwen_hip.h)
+CONTRACT_NAMES = {"3xbf16": CONTRACT_BF16X3, "bf16x3": CONTRACT_BF16X3, "fp32": CONTRACT_F32, "bf16x6": CONTRACT_BF16X6}
 KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN, KIND_SMALL, KIND_WIDE = 2, 3, 4, 5, 6, 8
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+EW_MUL, EW_ADD = 0, 1
 KIND_NAMES = {KIND_PROPAGATE: "propagate", KIND_LINEAR: "linear", KIND_LAYER: "layer",
               KIND_CHAIN: "chain", KIND_SMALL: "small", KIND_WIDE: "wide"}
 
@@ -74,14 +78,15 @@ SIGNATURES = {
     "gwen_gcn_layer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _int, _int, _vp]),
     "gwen_gcn_layer_supported": (_int, [_i64, _i64]),
-    "gwen_gcn_chain_supported": (_int, [_i64, _i64, _i64, _int]),
+    "gwen_gcn_chain_supported": (_int, [_i64, _i64, _i64, _int, _int]),
     "gwen_gcn_chain_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,
-                                  _int, _i64, _i64, _i64, _vp]),
+                                  _int, _i64, _i64, _i64, _int, _vp]),
     "gwen_gcn_tiles64_count": (_i64, [_i64]),
     "gwen_gcn_tiles64": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gwen_gcn_wide_supported": (_int, [_i64, _i64]),
     "gwen_gcn_wide_preferred": (_int, [_i64, _i64, _i64, _i64]),
-    "gwen_gcn_wide_layer_f32": (_int, [_vp] * 7 + [_i64] * 8 + [_int, _i64, _vp]),
+    "gwen_gcn_wide_contract_supported": (_int, [_i64, _i64, _int]),
+    "gwen_gcn_wide_layer_f32": (_int, [_vp] * 7 + [_i64] * 8 + [_int, _i64, _int, _vp]),
     "gwen_gnn_forward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
     "gwen_gnn_forward_f32": (_int, [C.POINTER(GraphDesc), C.POINTER(LayerDesc), C.c_int32, _vp, _vp,
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
@@ -107,12 +112,12 @@ SIGNATURES = {
     "gwen_reduce_chunks_batched": (_int, [_vp, C.c_int32, _vp]),
     "gwen_transpose_batched": (_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "gwen_gcn_small_pad": (_int, [_i64]),
-    "gwen_gcn_small_supported": (_int, [_i64, _i64, _i64]),
+    "gwen_gcn_small_supported": (_int, [_i64, _i64, _i64, _int]),
     "gwen_gcn_small_workspace_floats": (_i64, [_i64, _i64, _i64, _i64]),
     "gwen_gcn_dense_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "gwen_gcn_small_pack_bytes": (_i64, [_i64, _i64]),
     "gwen_gcn_small_pack_f32": (_int, [_vp, _i64, _i64, _vp, _vp]),
-    "gwen_gcn_small_layer_f32": (_int, [_vp] * 6 + [_i64] * 6 + [_int, _vp, _i64, _vp]),
+    "gwen_gcn_small_layer_f32": (_int, [_vp] * 6 + [_i64] * 6 + [_int, _vp, _i64, _int, _vp]),
     "gwen_mlp2_supported": (_int, [_i64]),
     "gwen_edge_tiles_count": (_i64, [_i64, _i64]),
     "gwen_edge_tiles": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -120,6 +125,9 @@ SIGNATURES = {
                               _vp, _i64, _int, _vp, C.c_size_t, _vp]),
     "gwen_mlp2_workspace_bytes": (_i64, [_i64]),
     "gwen_mlp2_rows": (_int, [_i64]),
+    "gwen_act_pair_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _vp]),
+    "gwen_gather_add_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "gwen_ew_f32": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "gwen_masked_l1_workspace_floats": (_i64, []),
     "gwen_masked_l1_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
 }

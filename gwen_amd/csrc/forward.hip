@@ -22,6 +22,13 @@ inline int resolve_order(const gwen_layer_desc &L) {
   return L.order;
 }
 
+// contraction of a layer's dense part: AUTO / FUSED layers carry it (bf16x3 or bf16x6), explicit orders are fp32
+inline int contract_of(const gwen_layer_desc &L) {
+  if (L.order == GWEN_ORDER_AUTO || L.order == GWEN_ORDER_FUSED)
+    return L.contract == GWEN_CONTRACT_BF16X6 ? GWEN_CONTRACT_BF16X6 : GWEN_CONTRACT_BF16X3;
+  return GWEN_CONTRACT_F32;
+}
+
 inline int64_t round4(int64_t v) { return (v + 3) / 4 * 4; }
 
 int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t n, Plan *P) {
@@ -29,6 +36,7 @@ int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t
   for (int32_t i = 0; i < n; ++i) {
     const gwen_layer_desc &L = layers[i];
     if (L.fin < 0 || L.fout < 0) return GWEN_EINVAL;
+    if (L.contract != GWEN_CONTRACT_BF16X3 && L.contract != GWEN_CONTRACT_BF16X6) return GWEN_EINVAL;
     if (i > 0 && layers[i - 1].fout != L.fin) return GWEN_EINVAL;
     const int o = resolve_order(L);
     if ((o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) &&
@@ -106,8 +114,9 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
 #define GWEN_TRY(expr) do { int _r = (expr); if (_r != GWEN_OK) return _r; } while (0)
 
   // AUTO layer whose widths K4 takes and that shrinks: worth gathering at fout, i.e. transform-first
-  auto shrinking_auto = [&](int32_t i) {      // never while training: every layer's output must exist
-    return !acts && i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin;
+  auto shrinking_auto = [&](int32_t i, int contract) {   // never while training: every layer's output must exist
+    return !acts && i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin &&
+           contract_of(layers[i]) == contract;               // one contraction per chained kernel
   };
   const bool have_grouped = g_col && g_val;          // g_rowptr NULL = uniform layout
 
@@ -116,14 +125,15 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
   bool small = dense != nullptr;
   for (int32_t i = 0; i < n_layers && small; ++i)
     small = layers[i].order == GWEN_ORDER_AUTO &&
-            gwen_gcn_small_supported(N, layers[i].fin, layers[i].fout);
+            gwen_gcn_small_supported(N, layers[i].fin, layers[i].fout, contract_of(layers[i]));
   if (small) {
     for (int32_t i = 0; i < n_layers; ++i) {
       const gwen_layer_desc &L = layers[i];
       float *dst = acts ? acts[i] : (i + 1 == n_layers ? out : buf[i & 1]);
       GWEN_TRY(before(GWEN_KIND_SMALL, i, L.fin, L.fout));
       GWEN_TRY(gwen_gcn_small_layer_f32(dense, cur, L.W, L.packed, L.bias, dst, N, L.fin, L.fout, members,
-                                        N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats, stream));
+                                        N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats, contract_of(L),
+                                        stream));
       GWEN_TRY(after());
       cur = dst;
     }
@@ -138,20 +148,22 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
     const int64_t fi = L.fin, fo = L.fout;
     if (projected) {
       // layer i: propagate at width fo with its bias/ReLU; chain layer i+1's projection if it shrinks
-      const bool chain = !last && have_grouped && shrinking_auto(i + 1) &&
-                         gwen_gcn_chain_supported(fo, layers[i + 1].fout, 0, 1);
+      const int cn = last ? 0 : contract_of(layers[i + 1]);
+      const bool chain = !last && have_grouped && shrinking_auto(i + 1, cn) &&
+                         gwen_gcn_chain_supported(fo, layers[i + 1].fout, 0, 1, cn);
       float *dst = acts ? acts[i] : ((last) ? out : buf[nbuf++ & 1]);
       if (chain) {
         GWEN_TRY(before(GWEN_KIND_CHAIN, i, fo, layers[i + 1].fout));
         GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, layers[i + 1].W, nullptr, L.bias,
                                     dst, N, fo, layers[i + 1].fout, 0, 1, L.relu, members, N * fo,
-                                    N * layers[i + 1].fout, stream));
+                                    N * layers[i + 1].fout, cn, stream));
         GWEN_TRY(after());
         projected = true;
-      } else if (have_grouped && gwen_gcn_chain_supported(fo, 0, 0, 1)) {
+      } else if (have_grouped && gwen_gcn_chain_supported(fo, 0, 0, 1, GWEN_CONTRACT_BF16X3)) {
         GWEN_TRY(before(GWEN_KIND_CHAIN, i, fo, fo));
         GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, nullptr, nullptr, L.bias, dst, N,
-                                    fo, 0, 0, 1, L.relu, members, N * fo, N * fo, stream));
+                                    fo, 0, 0, 1, L.relu, members, N * fo, N * fo, GWEN_CONTRACT_BF16X3,
+                                    stream));           // no contraction in this form
         GWEN_TRY(after());
         projected = false;
       } else {
@@ -165,16 +177,18 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
       continue;
     }
     const int o = resolve_order(L);
+    const int cc = contract_of(L);
     if (o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) {
-      const bool chain = have_grouped && L.order == GWEN_ORDER_AUTO && !last && shrinking_auto(i + 1) &&
-                         gwen_gcn_chain_supported(fi, fo, layers[i + 1].fout, 0);
+      const bool chain = have_grouped && L.order == GWEN_ORDER_AUTO && !last && shrinking_auto(i + 1, cc) &&
+                         gwen_gcn_chain_supported(fi, fo, layers[i + 1].fout, 0, cc);
       if (!chain && L.order == GWEN_ORDER_AUTO && have_tiles &&
-          gwen_gcn_wide_preferred(N, members, fi, fo)) {        // K8: the same arithmetic as K4, tile-staged
+          gwen_gcn_wide_preferred(N, members, fi, fo) && gwen_gcn_wide_contract_supported(fi, fo, cc) &&
+          (cc == GWEN_CONTRACT_BF16X3 || graph->union_max <= 128)) {   // K8: K4's arithmetic, tile-staged
         float *dst = acts ? acts[i] : (last ? out : buf[nbuf++ & 1]);
         GWEN_TRY(before(GWEN_KIND_WIDE, i, fi, fo));
         GWEN_TRY(gwen_gcn_wide_layer_f32(graph->t_rows, graph->t_lid, graph->t_val, cur, L.W, L.bias, dst,
                                          N, N, fi, fo, fo, members, N * fi, N * fo, L.relu,
-                                         graph->union_max, stream));
+                                         graph->union_max, cc, stream));
         GWEN_TRY(after());
         cur = dst;
         continue;
@@ -186,21 +200,21 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
         GWEN_TRY(before(GWEN_KIND_CHAIN, i, fi, layers[i + 1].fout));
         GWEN_TRY(gwen_gcn_chain_f32(g_rowptr, g_col, g_val, cur, L.W, layers[i + 1].W, L.bias, dst,
                                     N, fi, fo, layers[i + 1].fout, 0, L.relu, members, N * fi,
-                                    N * layers[i + 1].fout, stream));
+                                    N * layers[i + 1].fout, cc, stream));
         GWEN_TRY(after());
         projected = true;
       } else {
         GWEN_TRY(before(GWEN_KIND_LAYER, i, fi, fo));
         GWEN_TRY(gwen_gcn_layer_f32(g_rowptr, g_col, g_val, cur, L.W, L.bias, dst, N, fi, fo, fi, fo,
-                                    members, N * fi, N * fo, L.relu, o == GWEN_ORDER_FUSED_EXACT,
-                                    stream));
+                                    members, N * fi, N * fo, L.relu,
+                                    o == GWEN_ORDER_FUSED_EXACT ? GWEN_CONTRACT_F32 : cc, stream));
         GWEN_TRY(after());
       }
       cur = dst;
     } else if (o == GWEN_ORDER_TRANSFORM_FIRST) {
       float *dst = acts ? acts[i] : (last ? out : buf[nbuf++ & 1]);
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
-      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, L.order != GWEN_ORDER_AUTO, lin_ws,
+      GWEN_TRY(gwen_gcn_linear_f32(cur, L.W, nullptr, tmp, rows, fi, fo, fi, fo, 0, cc, lin_ws,
                                    P.lin_floats, stream));
       GWEN_TRY(after());
       GWEN_TRY(before(GWEN_KIND_PROPAGATE, i, fo, fo));
@@ -215,7 +229,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
                                       N * fi, N * fi, 0, stream));
       GWEN_TRY(after());
       GWEN_TRY(before(GWEN_KIND_LINEAR, i, fi, fo));
-      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, L.order != GWEN_ORDER_AUTO,
+      GWEN_TRY(gwen_gcn_linear_f32(tmp, L.W, L.bias, dst, rows, fi, fo, fi, fo, L.relu, cc,
                                    lin_ws, P.lin_floats, stream));
       GWEN_TRY(after());
       cur = dst;

@@ -25,34 +25,26 @@
 //   the 6-layer model; tolerance 1e-4).  The split is done once per element when the aggregated row
 //   is written to LDS (hi and lo tiles, row pitch Fin/2+8 dwords => conflict-free 16-B reads).
 //   It exists because the exact fp32 MFMA (1/16 of the bf16 rate) cost 7 of a 64->64 layer's 28 us.
+// Contraction (exact = 2): "bf16x6" -- three images per operand, six MFMAs per k-step: 24 bits per operand, the
+//   fp32-class default of the host API (split.h); one more LDS image of the tile.
 // Contraction (exact = 1): v_mfma_f32_16x16x4_f32 on an fp32 tile (k-permutation k = 8q+2(lane>>4)+s,
 //   row pitch Fin+4 floats => conflict-free 8-B reads): bit-exact fp32 fmaf chains.
 // Blocks are remapped so that the blocks sharing an XCD (blockIdx % 8) own neighbouring rows.
 #include "common.h"
 #include "gather_rows.h"
+#include "split.h"
 
 namespace {
 
 constexpr int kTile = 16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using gwen::bf16x4;
+using gwen::bf16x8;
+template <int K> using BF = gwen::BFv<K>;
 
-template <int K> struct BF;
-template <> struct BF<8> { using T = bf16x8; };
-template <> struct BF<4> { using T = bf16x4; };
-
-template <int K>
-__device__ inline void split_bf16(const float (&x)[K], typename BF<K>::T &hi, typename BF<K>::T &lo) {
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const __bf16 h = (__bf16)x[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(x[i] - (float)h);
-  }
-}
-
-template <int FIN, int FOUT, bool SPLIT, int BRMIN = 32>
+// NS: bf16 images per operand (2: bf16x3, 3: bf16x6, split.h); 0: the fp32-input MFMA
+template <int FIN, int FOUT, int NS, int BRMIN = 32>
 struct Cfg {
+  static constexpr bool SPLIT = NS > 0;
   static constexpr int G = FIN / 4, R = 64 / G;            // lanes per gathered row, rows per wave pass
   static constexpr int NJ = FOUT / 16;                     // 16-column output tiles
   static constexpr int NWB = NJ > 8 ? 16 : (NJ > 4 ? 8 : 4);   // waves per block: one per column tile
@@ -66,7 +58,7 @@ struct Cfg {
   static constexpr int KS = FIN / (4 * KF);                // split: MFMA k-steps
   static constexpr int PF = FIN + 4;                       // exact: tile row pitch (floats)
   static constexpr int PB = ((FIN / 2) % 16 == 8 ? FIN / 2 : FIN / 2 + 8) * 2;   // split: pitch (bf16)
-  static constexpr size_t lds_bytes = SPLIT ? (size_t)2 * BR * PB * 2 : (size_t)BR * PF * 4;
+  static constexpr size_t lds_bytes = SPLIT ? (size_t)NS * BR * PB * 2 : (size_t)BR * PF * 4;
   static_assert(NWB % NJ == 0, "waves must tile the output columns");
   static_assert(BR % RB == 0 && BR % kTile == 0, "a block is whole gather passes and whole row tiles");
 };
@@ -74,18 +66,20 @@ struct Cfg {
 // BWD (the layer's backward, gwen_gcn_layer_bwd_f32): the aggregated rows are also stored (agg_out: the
 // operand of grad_W) and the result is masked by mask > 0 (the ReLU of the layer below), so the launch
 // returns the gradient the next backward launch starts from.
-template <int FIN, int FOUT, bool SPLIT, int BRMIN, bool UNI = false, bool BWD = false>
+template <int FIN, int FOUT, int NS, int BRMIN, bool UNI = false, bool BWD = false>
 __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void k_layer(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int64_t ldo,
     int64_t mstride_x, int64_t mstride_o, int relu, float *__restrict__ agg_out = nullptr,
     const float *__restrict__ mask = nullptr) {
-  using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
+  using C = Cfg<FIN, FOUT, NS, BRMIN>;
+  constexpr bool SPLIT = NS > 0;
+  constexpr int NI = SPLIT ? NS : 1;
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
   float *tile = reinterpret_cast<float *>(lds_raw);                      // exact: [BR][PF] fp32
-  __bf16 *thi = reinterpret_cast<__bf16 *>(lds_raw);                     // split: [BR][PB] hi
-  __bf16 *tlo = thi + C::BR * C::PB;                                     //        [BR][PB] lo
+  __bf16 *timg = reinterpret_cast<__bf16 *>(lds_raw);                    // split: NS images [BR][PB]
+  constexpr int kImg = C::BR * C::PB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int gl = lane % C::G, gr = lane / C::G;
   const int mi = lane & 15, mh = lane >> 4;
@@ -103,7 +97,7 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   const int j = wave % C::NJ;
   const float *wrow = W + (int64_t)(j * 16 + mi) * FIN;
   float2_t bfr[SPLIT ? 1 : C::NQ];
-  typename BF<C::KF>::T bhi[SPLIT ? C::KS : 1], blo[SPLIT ? C::KS : 1];
+  typename BF<C::KF>::T bw[SPLIT ? C::KS : 1][NI];                       // W images per k-step
   if constexpr (SPLIT) {
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
@@ -115,7 +109,7 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
 #pragma unroll
         for (int e = 0; e < 4; ++e) wv[i + e] = w4[e];
       }
-      split_bf16<C::KF>(wv, bhi[ks], blo[ks]);
+      gwen::split_images<C::KF, NI>(wv, bw[ks]);
     }
   } else {
 #pragma unroll
@@ -143,10 +137,11 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
         }
         if constexpr (SPLIT) {
           const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
-          bf16x4 h4, l4;
-          split_bf16<4>(a4, h4, l4);
-          *reinterpret_cast<bf16x4 *>(thi + lr * C::PB + gl * 4) = h4;
-          *reinterpret_cast<bf16x4 *>(tlo + lr * C::PB + gl * 4) = l4;
+          bf16x4 im[NI];
+          gwen::split_images<4, NI>(a4, im);
+#pragma unroll
+          for (int s_ = 0; s_ < NI; ++s_)
+            *reinterpret_cast<bf16x4 *>(timg + s_ * kImg + lr * C::PB + gl * 4) = im[s_];
         } else {
           *reinterpret_cast<float4_t *>(tile + lr * C::PF + gl * 4) = acc;
         }
@@ -162,17 +157,11 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         using FT = typename BF<C::KF>::T;
-        const FT ahi = *reinterpret_cast<const FT *>(thi + arow + C::KF * (4 * ks + mh));
-        const FT alo = *reinterpret_cast<const FT *>(tlo + arow + C::KF * (4 * ks + mh));
-        if constexpr (C::KF == 8) {
-          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ks], alo, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ks], ahi, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ks], ahi, d, 0, 0, 0);
-        } else {
-          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bhi[ks], alo, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(blo[ks], ahi, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bhi[ks], ahi, d, 0, 0, 0);
-        }
+        FT a[NI];
+#pragma unroll
+        for (int s_ = 0; s_ < NI; ++s_)
+          a[s_] = *reinterpret_cast<const FT *>(timg + s_ * kImg + arow + C::KF * (4 * ks + mh));
+        d = gwen::mma_split<C::KF, NI>(bw[ks], a, d);
       }
     } else {
       const float *ap = tile + (tt * kTile + mi) * C::PF + 2 * mh;
@@ -205,17 +194,17 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   }
 }
 
-template <int FIN, int FOUT, bool SPLIT, int BRMIN>
+template <int FIN, int FOUT, int NS, int BRMIN>
 int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
                 const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
                 int64_t msx, int64_t mso, int relu, hipStream_t st, bool probe, int64_t *resident_out,
                 float *agg_out = nullptr, const float *mask = nullptr, bool bwd = false) {
-  using C = Cfg<FIN, FOUT, SPLIT, BRMIN>;
+  using C = Cfg<FIN, FOUT, NS, BRMIN>;
   static int per_cu = 0;
   if (per_cu == 0) {
     int nbk = 0;
     GWEN_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &nbk, reinterpret_cast<const void *>(&k_layer<FIN, FOUT, SPLIT, BRMIN, true>), C::NWB * 64, 0));
+        &nbk, reinterpret_cast<const void *>(&k_layer<FIN, FOUT, NS, BRMIN, true>), C::NWB * 64, 0));
     per_cu = nbk < 1 ? 1 : nbk;
   }
   const int64_t resident = (int64_t)256 * per_cu;
@@ -224,35 +213,35 @@ int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, con
   int64_t blocks = (N + C::BR - 1) / C::BR;
   if (FIN * FOUT >= 128 * 128 && blocks > resident) blocks = resident;   // wide layer: one resident set
   dim3 grid((unsigned)blocks, (unsigned)members);
-  if constexpr (SPLIT) {
+  if constexpr (NS == 2) {          // the backward runs on the bf16x3 contraction
     if (bwd) {
       if (!rowptr)
-        k_layer<FIN, FOUT, SPLIT, BRMIN, true, true><<<grid, C::NWB * 64, 0, st>>>(
+        k_layer<FIN, FOUT, NS, BRMIN, true, true><<<grid, C::NWB * 64, 0, st>>>(
             rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask);
       else
-        k_layer<FIN, FOUT, SPLIT, BRMIN, false, true><<<grid, C::NWB * 64, 0, st>>>(
+        k_layer<FIN, FOUT, NS, BRMIN, false, true><<<grid, C::NWB * 64, 0, st>>>(
             rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask);
       GWEN_LAUNCH_CHECK();
       return GWEN_OK;
     }
   }
   if (!rowptr)      // uniform layout: row r is the group at 8 r
-    k_layer<FIN, FOUT, SPLIT, BRMIN, true><<<grid, C::NWB * 64, 0, st>>>(
+    k_layer<FIN, FOUT, NS, BRMIN, true><<<grid, C::NWB * 64, 0, st>>>(
         rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu);
   else
-    k_layer<FIN, FOUT, SPLIT, BRMIN, false><<<grid, C::NWB * 64, 0, st>>>(
+    k_layer<FIN, FOUT, NS, BRMIN, false><<<grid, C::NWB * 64, 0, st>>>(
         rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
 
-template <int FIN, int FOUT, bool SPLIT>
+template <int FIN, int FOUT, int NS>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st, float *agg_out = nullptr,
            const float *mask = nullptr, bool bwd = false) {
 #define GWEN_ROWS(BRV, PROBE, RES)                                                                  \
-  launch_rows<FIN, FOUT, SPLIT, BRV>(rowptr, col, val, x, W, bias, out, N, ldo, members, msx, mso,  \
+  launch_rows<FIN, FOUT, NS, BRV>(rowptr, col, val, x, W, bias, out, N, ldo, members, msx, mso,  \
                                      relu, st, PROBE, RES, agg_out, mask, bwd)
   if constexpr (FIN <= 64 && FOUT <= 64) {
     // Narrow layers run as ONE round of co-resident blocks when a block size makes that possible: with
@@ -264,7 +253,7 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
     const int64_t work = N * members;
     { const int rc_ = GWEN_ROWS(64, true, &res); if (rc_ != GWEN_OK) return rc_; }
     if ((work + 63) / 64 <= res || members > 1) return GWEN_ROWS(64, false, nullptr);
-    constexpr int RB = Cfg<FIN, FOUT, SPLIT, 64>::RB;      // a block is whole gather passes of RB rows
+    constexpr int RB = Cfg<FIN, FOUT, NS, 64>::RB;      // a block is whole gather passes of RB rows
     if constexpr (96 % RB == 0) {
       { const int rc_ = GWEN_ROWS(96, true, &res); if (rc_ != GWEN_OK) return rc_; }
       if ((N + 95) / 96 <= res) return GWEN_ROWS(96, false, nullptr);
@@ -299,7 +288,7 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
                                   int64_t N, int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldo,
                                   int64_t members, int64_t mstride_x, int64_t mstride_o, int relu,
                                   int exact, gwen_stream_t stream_) {
-  if (N < 0 || members < 0 || ldx < Fin || ldo < Fout) return GWEN_EINVAL;
+  if (N < 0 || members < 0 || ldx < Fin || ldo < Fout || exact < 0 || exact > 2) return GWEN_EINVAL;
   if (!gwen_gcn_layer_supported(Fin, Fout)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
   if (!col || !val || !x || !W || !out || x == out) return GWEN_EINVAL;   // rowptr NULL = uniform
@@ -311,10 +300,14 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
   hipStream_t st = gwen_stream(stream_);
 #define GWEN_L(FI, FO)                                                                           \
   if (Fin == FI && Fout == FO)                                                                   \
-    return exact ? launch<FI, FO, false>(rowptr, col, val, x, W, bias, out, N, ldo, members,     \
-                                         mstride_x, mstride_o, relu, st)                         \
-                 : launch<FI, FO, true>(rowptr, col, val, x, W, bias, out, N, ldo, members,      \
-                                        mstride_x, mstride_o, relu, st)
+    return exact == GWEN_CONTRACT_F32                                                            \
+               ? launch<FI, FO, 0>(rowptr, col, val, x, W, bias, out, N, ldo, members, mstride_x, \
+                                   mstride_o, relu, st)                                          \
+               : (exact == GWEN_CONTRACT_BF16X6                                                  \
+                      ? launch<FI, FO, 3>(rowptr, col, val, x, W, bias, out, N, ldo, members,    \
+                                          mstride_x, mstride_o, relu, st)                        \
+                      : launch<FI, FO, 2>(rowptr, col, val, x, W, bias, out, N, ldo, members,    \
+                                          mstride_x, mstride_o, relu, st))
   GWEN_L(16, 16); GWEN_L(16, 32); GWEN_L(16, 64); GWEN_L(16, 128);
   GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);
   GWEN_L(64, 16); GWEN_L(64, 32); GWEN_L(64, 64); GWEN_L(64, 128);
@@ -345,7 +338,7 @@ extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_
   hipStream_t st = gwen_stream(stream_);
 #define GWEN_L(FI, FO)                                                                           \
   if (Fg == FI && Fx == FO)                                                                      \
-    return launch<FI, FO, true>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,     \
+    return launch<FI, FO, 2>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,        \
                                 N * Fg, N * Fx, 0, st, gh, mask, true)
   GWEN_L(16, 16); GWEN_L(16, 32); GWEN_L(16, 64); GWEN_L(16, 128);
   GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);

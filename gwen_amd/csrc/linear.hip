@@ -12,6 +12,7 @@
 // (two 32x32 accumulators); K is walked in slabs of 32 staged through LDS with rows padded to 33
 // floats so the per-k-step ds_read_b32 of 32 different rows is bank-conflict free.
 #include "common.h"
+#include "split.h"
 
 namespace {
 
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(kThreads) void k_linear(const float *__restrict__ x
 // Tile 128 x 128, K slabs of 32; operands are split once when they are staged into LDS (hi and lo
 // images, row pitch 48 bf16 => conflict-free 16-B fragment reads); wave = 32 rows x 128 columns.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using gwen::bf16x4;
+using gwen::bf16x8;
 constexpr int SBM = 128, SBN = 128, SBK = 32, SPB = 48;
 
 // One thread's share of a 128-row x 32-deep fp32 slab: 4 x 16 B, rows idx/8, k (idx%8)*4.
@@ -129,29 +130,25 @@ __device__ inline void slab_load(const float *__restrict__ g, int64_t ld, int64_
   }
 }
 
-// split the slab share into bf16 hi/lo and park it in the LDS images [128][SPB]
-__device__ inline void slab_store(const float4_t (&v)[4], __bf16 *__restrict__ hi,
-                                  __bf16 *__restrict__ lo) {
+// split the slab share into NS bf16 images and park them in the LDS images NS x [128][SPB]
+template <int NS>
+__device__ inline void slab_store(const float4_t (&v)[4], __bf16 *__restrict__ img) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = threadIdx.x + i * kThreads;
     const int r = idx >> 3, kq = (idx & 7) * 4;
-    bf16x4 h4, l4;
+    const float f4[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+    bf16x4 im[NS];
+    gwen::split_images<4, NS>(f4, im);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const __bf16 h = (__bf16)v[i][e];
-      h4[e] = h;
-      l4[e] = (__bf16)(v[i][e] - (float)h);
-    }
-    *reinterpret_cast<bf16x4 *>(hi + r * SPB + kq) = h4;
-    *reinterpret_cast<bf16x4 *>(lo + r * SPB + kq) = l4;
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4 *>(img + s * 128 * SPB + r * SPB + kq) = im[s];
   }
 }
 
 // NCT = 16-column tiles per block (8: 128 columns; 4: 64 columns for narrow outputs).
 // The next slab's global loads are issued before the current slab's MFMAs and parked in LDS after
 // them, so their latency hides under the matrix work instead of standing in front of it.
-template <bool VEC, int NCT>
+template <bool VEC, int NCT, int NS>
 __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restrict__ x,
                                                            const float *__restrict__ W,
                                                            const float *__restrict__ bias,
@@ -160,8 +157,9 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
                                                            int64_t ldh, int relu, int kchunk) {
   // split-K: blockIdx.z contracts k in [z * kchunk, min(Fin, (z+1) * kchunk)) and writes its RAW partial
   // product to slab z of h (h is then the workspace, ldh = Fout; bias/ReLU happen in the reduction)
-  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * 128 * SPB];
-  __bf16 *ahi = lds, *alo = lds + 128 * SPB, *bhi = lds + 2 * 128 * SPB, *blo = lds + 3 * 128 * SPB;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NS * 128 * SPB];
+  constexpr int kImg = 128 * SPB;
+  __bf16 *aimg = lds, *bimg = lds + NS * kImg;            // NS images of the x slab, NS of the W slab
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mi = lane & 15, mh = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * SBM;
@@ -180,8 +178,8 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
   float4_t pa[4], pb[4];
   slab_load<VEC>(x, ldx, row0, rows, k_lo, k_hi, pa);
   slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout), k_lo, k_hi, pb);
-  slab_store(pa, ahi, alo);
-  slab_store(pb, bhi, blo);
+  slab_store<NS>(pa, aimg);
+  slab_store<NS>(pb, bimg);
   __syncthreads();
   for (int k0 = k_lo; k0 < k_hi; k0 += SBK) {
     const bool more = k0 + SBK < k_hi;
@@ -189,29 +187,32 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
     slab_load<VEC>(x, ldx, row0, rows, k0 + SBK, k_hi, pa);
     slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout),
                    k0 + SBK, k_hi, pb);
-    bf16x8 fah[2], fal[2];
+    bf16x8 fa[2][NS];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int off = (wave * 32 + rt * 16 + mi) * SPB + 8 * mh;
-      fah[rt] = *reinterpret_cast<const bf16x8 *>(ahi + off);
-      fal[rt] = *reinterpret_cast<const bf16x8 *>(alo + off);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fa[rt][s] = *reinterpret_cast<const bf16x8 *>(aimg + s * kImg + off);
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const int off = (ct * 16 + mi) * SPB + 8 * mh;
-      const bf16x8 fbh = *reinterpret_cast<const bf16x8 *>(bhi + off);
-      const bf16x8 fbl = *reinterpret_cast<const bf16x8 *>(blo + off);
+      bf16x8 fb[NS];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[rt], fbh, acc[rt][ct], 0, 0, 0);
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[rt], fbl, acc[rt][ct], 0, 0, 0);
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[rt], fbh, acc[rt][ct], 0, 0, 0);
-      }
+      for (int s = 0; s < NS; ++s) fb[s] = *reinterpret_cast<const bf16x8 *>(bimg + s * kImg + off);
+      // terms (x image t - i) . (W image i), from the smallest to hi . hi (split.h's order with x as the A operand)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = NS - 1; t >= 0; --t)
+#pragma unroll
+          for (int i = 0; i <= t; ++i)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt][t - i], fb[i], acc[rt][ct], 0, 0, 0);
     }
     __syncthreads();                       // every wave is done reading this slab
     if (more) {
-      slab_store(pa, ahi, alo);
-      slab_store(pb, bhi, blo);
+      slab_store<NS>(pa, aimg);
+      slab_store<NS>(pb, bimg);
       __syncthreads();
     }
   }
@@ -264,9 +265,9 @@ inline int splitk_factor(int64_t rows, int64_t Fin, int64_t Fout) {
 
 }  // namespace
 
-// wide.hip: the K8 pipeline without a graph (tall inputs, Fin and Fout in {64, 128, 256})
+// wide.hip: the K8 pipeline without a graph (tall inputs, Fin and Fout in {64, 128, 256}; bf16x6 up to Fin = 128)
 int gwen_wide_dense_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows, int64_t Fin,
-                        int64_t Fout, int64_t ldx, int64_t ldh, int relu, hipStream_t st);
+                        int64_t Fout, int64_t ldx, int64_t ldh, int relu, int contract, hipStream_t st);
 
 extern "C" int64_t gwen_gcn_linear_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout) {
   if (rows <= 0 || Fin <= 0 || Fout <= 0) return 0;
@@ -278,9 +279,11 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
                                    int64_t rows, int64_t Fin, int64_t Fout, int64_t ldx,
                                    int64_t ldh, int relu, int exact, float *workspace,
                                    int64_t workspace_floats, gwen_stream_t stream_) {
-  if (rows < 0 || Fin < 0 || Fout < 0 || ldx < Fin || ldh < Fout) return GWEN_EINVAL;
+  if (rows < 0 || Fin < 0 || Fout < 0 || ldx < Fin || ldh < Fout || exact < 0 || exact > 2) return GWEN_EINVAL;
   if (rows == 0 || Fout == 0) return GWEN_OK;
   if (!h || (Fin > 0 && (!x || !W))) return GWEN_EINVAL;
+  const bool x6 = exact == GWEN_CONTRACT_BF16X6;
+  exact = exact == GWEN_CONTRACT_F32;
   if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
   const bool vec = Fin % 4 == 0 && ldx % 4 == 0 && gwen_aligned(x, 16) && gwen_aligned(W, 16);
@@ -289,13 +292,13 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
   // (measured, tools/experiments/k3_time.py: 256 -> 256 on 100 002 rows 76 -> 58 us, on 400 008 rows 338 -> 231 us;
   // equal from ~16 000 rows down, where the 128 x 128 tiles of k_linear_split fill the chip as well)
   const bool tall = rows >= 16384;
-  if (!exact && tall && vec && (Fin == 64 || Fin == 128 || Fin == 256) && Fout % 64 == 0 && Fout <= 2048 &&
+  if (!exact && tall && vec && (Fin == 64 || Fin == 128 || (Fin == 256 && !x6)) && Fout % 64 == 0 && Fout <= 2048 &&
       ldh % 4 == 0 && gwen_aligned(h, 16) && (!bias || gwen_aligned(bias, 16)) &&
       rows * ldx * 4 < (int64_t(1) << 32) && x != h) {
     for (int64_t c0 = 0; c0 < Fout;) {
       const int64_t left = Fout - c0, g = left >= 256 ? 256 : left >= 128 ? 128 : 64;
       const int rc = gwen_wide_dense_f32(x, W + c0 * Fin, bias ? bias + c0 : nullptr, h + c0, rows, Fin, g, ldx,
-                                         ldh, relu, st);
+                                         ldh, relu, x6 ? GWEN_CONTRACT_BF16X6 : GWEN_CONTRACT_BF16X3, st);
       if (rc != GWEN_OK) return rc;
       c0 += g;
     }
@@ -312,9 +315,15 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
     dim3 sgrid((unsigned)sx, (unsigned)sy, (unsigned)nz);
     float *dst = nz > 1 ? workspace : h;
     const int64_t dld = nz > 1 ? Fout : ldh;
-#define GWEN_LS(V, T)                                                                             \
-  k_linear_split<V, T><<<sgrid, kThreads, 0, st>>>(x, W, bias, dst, rows, (int)Fin, (int)Fout, ldx, \
-                                                   dld, relu, kchunk)
+#define GWEN_LS(V, T)                                                                               \
+  do {                                                                                              \
+    if (x6)                                                                                         \
+      k_linear_split<V, T, 3><<<sgrid, kThreads, 0, st>>>(x, W, bias, dst, rows, (int)Fin, (int)Fout, ldx, \
+                                                          dld, relu, kchunk);                       \
+    else                                                                                            \
+      k_linear_split<V, T, 2><<<sgrid, kThreads, 0, st>>>(x, W, bias, dst, rows, (int)Fin, (int)Fout, ldx, \
+                                                          dld, relu, kchunk);                       \
+  } while (0)
     if (vec) { if (bn == 64) GWEN_LS(true, 4); else GWEN_LS(true, 8); }
     else     { if (bn == 64) GWEN_LS(false, 4); else GWEN_LS(false, 8); }
 #undef GWEN_LS

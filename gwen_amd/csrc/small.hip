@@ -20,40 +20,43 @@
 //   a long K (the C -> 1024 projection) is cut over blockIdx.z: partial h tiles go to a workspace and
 //   k_small_finish adds them in split order before the second contraction.
 #include "common.h"
+#include "split.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using gwen::bf16x8;
 
 // NP = padded node count: 128 (2 row tiles per wave) or 256 (4); pitch of the transposed h tile
 // NP + 8 bf16 => conflict-free 16-B reads
 constexpr int kMaxNodes = 256;
 inline int pad_nodes(int64_t N) { return N <= 128 ? 128 : 256; }
 
-__device__ inline void split8(const float4_t a, const float4_t b, bf16x8 &hi, bf16x8 &lo) {
+template <int NS>
+__device__ inline void split8n(const float4_t a, const float4_t b, bf16x8 (&im)[NS]) {
   const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)v[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(v[i] - (float)h);
-  }
+  gwen::split_images<8, NS>(v, im);
 }
 
-__device__ inline f32x4 mma3(const bf16x8 ahi, const bf16x8 alo, const bf16x8 bhi, const bf16x8 blo,
-                             f32x4 d) {
-  d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo, d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi, d, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi, d, 0, 0, 0);
+__device__ inline void split8(const float4_t a, const float4_t b, bf16x8 &hi, bf16x8 &lo) {
+  bf16x8 im[2];
+  split8n<2>(a, b, im);
+  hi = im[0];
+  lo = im[1];
+}
+
+// d += sum of image products a[i] . b[t - i], smallest terms first; NS = 2: (a0,b1) (a1,b0) (a0,b0)
+template <int NS>
+__device__ inline f32x4 mma_n(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x4 d) {
+  return gwen::mma_split<8, NS>(a, b, d);
 }
 
 // second contraction + bias + ReLU + store, from the h tile this lane holds in D layout
 // (d[rt][n]: row (2 wave + rt) 16 + mi, columns c0 + 16 n + 4 mh .. +3)
-template <int NP, int NC>
+template <int NP, int NC, int NS>
 __device__ inline void aggregate_store(f32x4 (&d)[NP / 64][NC], const float *__restrict__ dense,
                                        const float *__restrict__ bias, float *__restrict__ om,
-                                       int N, int Fout, int c0, int relu, __bf16 *hthi, __bf16 *htlo) {
-  constexpr int RT = NP / 64, PJ = NP + 8, KS = NP / 32;
+                                       int N, int Fout, int c0, int relu, __bf16 *ht) {
+  constexpr int RT = NP / 64, PJ = NP + 8, KS = NP / 32, kImg = 16 * NC * PJ;   // NS images of h^T, kImg apart
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
   // this lane's fragments of D (rows of its row tiles): the first k-step is requested before anything
   // else, every later one a step ahead of the MFMAs that use it
@@ -75,11 +78,14 @@ __device__ inline void aggregate_store(f32x4 (&d)[NP / 64][NC], const float *__r
     for (int n = 0; n < NC; ++n)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float v = d[rt][n][i];
-        const __bf16 h = (__bf16)v;
+        float r = d[rt][n][i];
         const int c = 16 * n + 4 * mh + i;
-        hthi[c * PJ + j] = h;
-        htlo[c * PJ + j] = (__bf16)(v - (float)h);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+          const __bf16 h = (__bf16)r;
+          ht[s_ * kImg + c * PJ + j] = h;
+          r = r - (float)h;
+        }
       }
   }
   __syncthreads();
@@ -91,19 +97,19 @@ __device__ inline void aggregate_store(f32x4 (&d)[NP / 64][NC], const float *__r
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) fetch_d(ks + 1, dn);
-    bf16x8 ahi[NC], alo[NC];
+    bf16x8 a[NC][NS];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const int off = (16 * n + mi) * PJ + 32 * ks + 8 * mh;
-      ahi[n] = *reinterpret_cast<const bf16x8 *>(hthi + off);
-      alo[n] = *reinterpret_cast<const bf16x8 *>(htlo + off);
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) a[n][s_] = *reinterpret_cast<const bf16x8 *>(ht + s_ * kImg + off);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      bf16x8 bhi, blo;
-      split8(dr[rt][0], dr[rt][1], bhi, blo);
+      bf16x8 b[NS];
+      split8n<NS>(dr[rt][0], dr[rt][1], b);
 #pragma unroll
-      for (int n = 0; n < NC; ++n) o[rt][n] = mma3(ahi[n], alo[n], bhi, blo, o[rt][n]);
+      for (int n = 0; n < NC; ++n) o[rt][n] = mma_n<NS>(a[n], b, o[rt][n]);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -128,7 +134,7 @@ __device__ inline void aggregate_store(f32x4 (&d)[NP / 64][NC], const float *__r
   }
 }
 
-template <int NP, int NC, bool SPLIT, bool PACKED>
+template <int NP, int NC, bool SPLIT, bool PACKED, int NS>
 __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
                                                const float *__restrict__ x,
                                                const float *__restrict__ W,
@@ -137,7 +143,8 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
                                                int kchunk, int relu, int64_t mstride_x,
                                                int64_t mstride_o) {
   constexpr int RT = NP / 64, PJ = NP + 8;
-  __shared__ __attribute__((aligned(16))) __bf16 ht[SPLIT ? 8 : 2 * 16 * NC * PJ];
+  static_assert(!PACKED || NS == 2, "the packed weight images are the two bf16x3 images");
+  __shared__ __attribute__((aligned(16))) __bf16 ht[SPLIT ? 8 : NS * 16 * NC * PJ];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
   int cb = blockIdx.x, sp = blockIdx.z;
   if (SPLIT && gridDim.y == 1 && gridDim.z % 8 == 0) {
@@ -201,16 +208,16 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
   for (int k = k0; k < k1; k += 32 * KU) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      bf16x8 xhi[RT], xlo[RT], whi[NC], wlo[NC];
+      bf16x8 xi[RT][NS], wi[NC][NS];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) split8(xr[u][rt][0], xr[u][rt][1], xhi[rt], xlo[rt]);
+      for (int rt = 0; rt < RT; ++rt) split8n<NS>(xr[u][rt][0], xr[u][rt][1], xi[rt]);
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
         if constexpr (PACKED) {
-          whi[n] = __builtin_bit_cast(bf16x8, wr[u][n][0]);
-          wlo[n] = __builtin_bit_cast(bf16x8, wr[u][n][1]);
+          wi[n][0] = __builtin_bit_cast(bf16x8, wr[u][n][0]);
+          wi[n][1] = __builtin_bit_cast(bf16x8, wr[u][n][1]);
         } else {
-          split8(wr[u][n][0], wr[u][n][1], whi[n], wlo[n]);
+          split8n<NS>(wr[u][n][0], wr[u][n][1], wi[n]);
         }
       }
       fetch(u, k + 32 * (KU + u));
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
 #pragma unroll
         for (int n = 0; n < NC; ++n)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) d[rt][n] = mma3(whi[n], wlo[n], xhi[rt], xlo[rt], d[rt][n]);
+          for (int rt = 0; rt < RT; ++rt) d[rt][n] = mma_n<NS>(wi[n], xi[rt], d[rt][n]);
       }
     }
   }
@@ -234,20 +241,19 @@ __global__ __launch_bounds__(256) void k_small(const float *__restrict__ dense,
               float4_t{d[rt][n][0], d[rt][n][1], d[rt][n][2], d[rt][n][3]};
     }
   } else {
-    aggregate_store<NP, NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
-                        ht + 16 * NC * PJ);
+    aggregate_store<NP, NC, NS>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht);
   }
 }
 
 // adds the partial h tiles in split order, then the second contraction
-template <int NP, int NC>
+template <int NP, int NC, int NS>
 __global__ __launch_bounds__(256) void k_small_finish(const float *__restrict__ dense,
                                                       const float *__restrict__ part,
                                                       const float *__restrict__ bias,
                                                       float *__restrict__ out, int N, int Fout,
                                                       int nsplit, int relu, int64_t mstride_o) {
   constexpr int RT = NP / 64, PJ = NP + 8;
-  __shared__ __attribute__((aligned(16))) __bf16 ht[2 * 16 * NC * PJ];
+  __shared__ __attribute__((aligned(16))) __bf16 ht[NS * 16 * NC * PJ];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, mi = lane & 15, mh = lane >> 4;
   const int c0 = blockIdx.x * 16 * NC, member = blockIdx.y;
   f32x4 d[RT][NC];
@@ -272,8 +278,7 @@ __global__ __launch_bounds__(256) void k_small_finish(const float *__restrict__ 
       d[rt][n] = f32x4{acc[0], acc[1], acc[2], acc[3]};
     }
   }
-  aggregate_store<NP, NC>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht,
-                      ht + 16 * NC * PJ);
+  aggregate_store<NP, NC, NS>(d, dense, bias, out + member * mstride_o, N, Fout, c0, relu, ht);
 }
 
 // dense[i][j] = sum of the stored weights of entries (i <- j), zero elsewhere (NP x NP); one thread per
@@ -332,13 +337,18 @@ inline Shape shape_for(int64_t N, int64_t Fin, int64_t Fout) {
 
 extern "C" int gwen_gcn_small_pad(int64_t N) { return N >= 1 && N <= kMaxNodes ? pad_nodes(N) : GWEN_EINVAL; }
 
-extern "C" int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout) {
+static int small_shape_ok(int64_t N, int64_t Fin, int64_t Fout) {
   return N >= 1 && N <= kMaxNodes && Fin >= 32 && Fin % 32 == 0 && Fout >= 16 && Fout % 16 == 0 ? 1 : 0;
+}
+
+extern "C" int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout, int contract) {
+  if (contract != GWEN_CONTRACT_BF16X3 && contract != GWEN_CONTRACT_BF16X6) return 0;
+  return small_shape_ok(N, Fin, Fout);
 }
 
 extern "C" int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin,
                                                    int64_t Fout) {
-  if (!gwen_gcn_small_supported(N, Fin, Fout) || members < 0) return 0;
+  if (!small_shape_ok(N, Fin, Fout) || members < 0) return 0;
   const Shape s = shape_for(N, Fin, Fout);
   return s.nsplit > 1 ? (int64_t)s.nsplit * members * N * Fout : 0;
 }
@@ -371,10 +381,12 @@ extern "C" int gwen_gcn_small_layer_f32(const float *dense, const float *x, cons
                                         const float *bias, float *out, int64_t N, int64_t Fin,
                                         int64_t Fout, int64_t members, int64_t mstride_x,
                                         int64_t mstride_o, int relu, float *workspace,
-                                        int64_t workspace_floats, gwen_stream_t stream_) {
-  if (members < 0 || !gwen_gcn_small_supported(N, Fin, Fout)) return GWEN_EINVAL;
+                                        int64_t workspace_floats, int contract, gwen_stream_t stream_) {
+  if (members < 0 || !gwen_gcn_small_supported(N, Fin, Fout, contract)) return GWEN_EINVAL;
   if (members == 0) return GWEN_OK;
-  if (!dense || !x || (!W && !packed) || !out || x == out || members > 65535) return GWEN_EINVAL;
+  const bool x6 = contract == GWEN_CONTRACT_BF16X6;
+  if (x6 && W) packed = nullptr;          // the packed images are the two of bf16x3: bf16x6 splits W itself
+  if (!dense || !x || (!W && !packed) || (x6 && !W) || !out || x == out || members > 65535) return GWEN_EINVAL;
   const void *al[] = {dense, x, W, packed, bias, out, workspace};
   for (const void *p : al)
     if (p && !gwen_aligned(p, 16)) return GWEN_EINVAL;
@@ -386,22 +398,29 @@ extern "C" int gwen_gcn_small_layer_f32(const float *dense, const float *x, cons
   const dim3 grid((unsigned)(Fout / (16 * s.nc)), (unsigned)members, (unsigned)s.nsplit);
   const dim3 fgrid((unsigned)(Fout / 16), (unsigned)members);   // the finish always 16 columns a block
   const float *wsrc = packed ? reinterpret_cast<const float *>(packed) : W;
-#define GWEN_K(NPV, NCV, SP, PK)                                                                     \
-  k_small<NPV, NCV, SP, PK><<<grid, 256, 0, st>>>(dense, x, wsrc, bias, out, workspace, (int)N,       \
-                                                  (int)Fin, (int)Fout, s.kchunk, relu, mstride_x,     \
-                                                  mstride_o)
+#define GWEN_K(NPV, NCV, SP, PK, NSV)                                                                \
+  k_small<NPV, NCV, SP, PK, NSV><<<grid, 256, 0, st>>>(dense, x, wsrc, bias, out, workspace, (int)N,  \
+                                                       (int)Fin, (int)Fout, s.kchunk, relu, mstride_x, \
+                                                       mstride_o)
+#define GWEN_F(NPV, NSV)                                                                             \
+  k_small_finish<NPV, 1, NSV><<<fgrid, 256, 0, st>>>(dense, workspace, bias, out, (int)N, (int)Fout,  \
+                                                     s.nsplit, relu, mstride_o)
 #define GWEN_S(NPV, NCV)                                                                             \
   if (pad_nodes(N) == NPV && s.nc == NCV) {                                                          \
     if (s.nsplit > 1) {                                                                              \
-      if (packed) GWEN_K(NPV, NCV, true, true); else GWEN_K(NPV, NCV, true, false);                  \
-      k_small_finish<NPV, 1><<<fgrid, 256, 0, st>>>(dense, workspace, bias, out, (int)N, (int)Fout,   \
-                                                    s.nsplit, relu, mstride_o);                      \
+      if (x6) GWEN_K(NPV, NCV, true, false, 3);                                                      \
+      else if (packed) GWEN_K(NPV, NCV, true, true, 2);                                              \
+      else GWEN_K(NPV, NCV, true, false, 2);                                                         \
+      if (x6) GWEN_F(NPV, 3); else GWEN_F(NPV, 2);                                                   \
     } else {                                                                                         \
-      if (packed) GWEN_K(NPV, NCV, false, true); else GWEN_K(NPV, NCV, false, false);                \
+      if (x6) GWEN_K(NPV, NCV, false, false, 3);                                                     \
+      else if (packed) GWEN_K(NPV, NCV, false, true, 2);                                             \
+      else GWEN_K(NPV, NCV, false, false, 2);                                                        \
     }                                                                                                \
   }
   GWEN_S(128, 1) GWEN_S(128, 4) GWEN_S(256, 1) GWEN_S(256, 2)
 #undef GWEN_S
+#undef GWEN_F
 #undef GWEN_K
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;

@@ -34,48 +34,44 @@
 // Numerics: identical to K4's 3xbf16 path term for term (same aggregation order, same split, same MFMA
 // sequence) -- tests compare the two bitwise.
 #include "common.h"
+#include "split.h"
 #include <type_traits>
 
 #ifndef WEAVE_VALU
 #define WEAVE_VALU 2
 #endif
-#ifndef K8_ROLES      // experiment: the two waves of a SIMD take the step's two halves in opposite order
-#define K8_ROLES 0
+#ifndef K8_ROLES      // -1: where it measured faster (Fin = 64); 0 / 1: never / always (variant builds)
+#define K8_ROLES (-1)
 #endif
 #ifndef K8_PRIO       // experiment: s_setprio around the MFMA half
 #define K8_PRIO 0
 #endif
-#ifndef K8_NT         // experiment: 1 = non-temporal output stores
-#define K8_NT 0
+#ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
+#define K8_NT (-1)
 #endif
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using gwen::bf16x4;
+using gwen::bf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRows = GWEN_TILE_ROWS;        // 64 destination rows per tile
 constexpr int kUCap = GWEN_TILE_UNION;       // 192 union slots per tile in t_rows
 constexpr int kFC = 64;                      // features per chunk
-constexpr int kStageAll = kUCap * kFC * 4 * 2;              // 98304 B of staging: 2 x 192 or 3 x 128 slots
 constexpr int kPB = 80;                      // A-chunk row pitch in bf16 (160 B: conflict-free 16-B reads)
-constexpr int kAImg = kRows * kPB * 2;       // one bf16 image (hi or lo) of a chunk: 10240 B
-constexpr int kABytes = 2 * kAImg;
+constexpr int kAImg = kRows * kPB * 2;       // one bf16 image of a chunk: 10240 B
 constexpr int kEntBytes = kRows * 8 * 4 + kRows * 8 * 2;   // weights fp32 + local ids u16 = 3072
-constexpr int kOffStage = 0;
-constexpr int kOffA = kOffStage + kStageAll;                // 98304
-constexpr int kOffEnt = kOffA + 2 * kABytes;                // 139264
-constexpr int kOffBias = kOffEnt + 3 * kEntBytes;           // 148480
-constexpr int kLds = kOffBias + 1024;                       // 149504
+// LDS of one block: (D + 1) stage buffers of KU slots x 256 B | 2 A chunks of NS images | 3 entry sets | bias
+constexpr int lds_bytes(int nstg, int ku, int ns) {
+  return nstg * ku * kFC * 4 + 2 * ns * kAImg + 3 * kEntBytes + 1024;
+}
 
-__device__ inline void split4(const float4_t &a, bf16x4 &hi, bf16x4 &lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __bf16 h = (__bf16)a[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(a[i] - (float)h);
-  }
+// aggregated rows -> NS bf16 images (split.h)
+template <int NS>
+__device__ inline void split4n(const float4_t &a, bf16x4 (&im)[NS]) {
+  const float f4[4] = {a[0], a[1], a[2], a[3]};
+  gwen::split_images<4, NS>(f4, im);
 }
 
 template <int N, typename F, int I = 0>
@@ -120,12 +116,14 @@ __device__ inline void wait_vmcnt(int n) {
 // DENSE: no graph -- the "union" of a tile is its own 64 rows and the aggregate is the row itself: the kernel is
 // then K3's 3xbf16 projection out = act(x W^T + b) for tall inputs (gwen_gcn_linear_f32 sends them here), with
 // x rows at pitch ldx.
-template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE>
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE, int NS>
 __global__ __launch_bounds__(NW * 64) void k_wide(
     const int32_t *__restrict__ t_rows, const uint16_t *__restrict__ t_lid,
     const float *__restrict__ t_val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
-    int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu, int32_t ldx) {
+    int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu, int32_t ldx, int nt) {
+  // ROLES (below): the two waves of a SIMD take the step's two halves in opposite order
+  constexpr bool ROLES = (K8_ROLES < 0 ? FIN == 64 : K8_ROLES != 0) && !DENSE && D == 1;
   constexpr int NSTG = D + 1;                           // stage buffers
   constexpr int kStageBytes = KU * kFC * 4;
   constexpr int NC = FIN / kFC;                         // chunks per tile
@@ -138,7 +136,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   constexpr int NP = kRows / (4 * NW);                  // aggregate passes per wave and chunk
   static_assert(NC >= 1 && 4 % TSTEP == 0 && (NJ % NW == 0 || NW % NJ == 0), "unsupported widths");
   static_assert(NQ * 4 * NW == KU && NP * 4 * NW == kRows, "waves must tile the union and the rows");
-  static_assert(NSTG * kStageBytes <= kStageAll, "stage buffers exceed their LDS region");
+  constexpr int kABytes = NS * kAImg;                   // one A chunk: NS images
+  constexpr int kOffStage = 0, kOffA = NSTG * kStageBytes, kOffEnt = kOffA + 2 * kABytes;
+  constexpr int kOffBias = kOffEnt + 3 * kEntBytes, kLds = lds_bytes(NSTG, KU, NS);
+  static_assert(kLds <= 160 * 1024, "the block's LDS exceeds a CU's");
   static_assert(!DENSE || KU == kRows, "a dense tile stages its own rows");
   const uint32_t row_pitch = DENSE ? (uint32_t)ldx * 4u : (uint32_t)(FIN * 4);
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   // ---- W fragments (this wave's CT x 16 output columns, all of Fin) -- as K4; bias -> LDS ---------------
   const int jw = NJ >= NW ? wave : wave % NJ;                  // this wave's column tiles: CT jw .. + CT - 1
   const int tt0 = NJ >= NW ? 0 : wave / NJ;                    // its first row tile
-  bf16x8 bhi[CT][KS], blo[CT][KS];
+  bf16x8 bw[CT][KS][NS];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int j = CT * jw + ct;                                // adjacent tiles: full 128-B lines per row
@@ -180,13 +181,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       const float *wp = wrow + 8 * (4 * ks + mh);
       const float4_t w0 = *reinterpret_cast<const float4_t *>(wp);
       const float4_t w1 = *reinterpret_cast<const float4_t *>(wp + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        __bf16 h = (__bf16)w0[e];
-        bhi[ct][ks][e] = h; blo[ct][ks][e] = (__bf16)(w0[e] - (float)h);
-        h = (__bf16)w1[e];
-        bhi[ct][ks][e + 4] = h; blo[ct][ks][e + 4] = (__bf16)(w1[e] - (float)h);
-      }
+      const float w8[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+      gwen::split_images<8, NS>(w8, bw[ct][ks]);
     }
   }
   {
@@ -197,7 +193,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)       // every global load above is waited for here, not inside the pipeline
-      asm volatile("" : "+v"(bhi[ct][ks]), "+v"(blo[ct][ks]));
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) asm volatile("" : "+v"(bw[ct][ks][s_]));
 
   // ---- pipeline pieces ------------------------------------------------------------------------------------
   // DMA of (tile g, chunk c) into stage[sb]; with c == 0 also the tile's entry weights / local ids into
@@ -259,11 +256,11 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       for (int p = 0; p < NP; ++p) {
         const int lr = 4 * NW * p + 4 * wave + mh;
         const float4_t a4 = *reinterpret_cast<const float4_t *>(stg + lr * (kFC * 4));
-        bf16x4 h4, l4;
-        split4(a4, h4, l4);
+        bf16x4 im[NS];
+        split4n<NS>(a4, im);
         char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
-        *reinterpret_cast<bf16x4 *>(a) = h4;
-        *reinterpret_cast<bf16x4 *>(a + kAImg) = l4;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
       }
       return;
     }
@@ -301,11 +298,11 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int lr = 4 * NW * p + 4 * wave + mh;
-      bf16x4 h4, l4;
-      split4(acc[p], h4, l4);
+      bf16x4 im[NS];
+      split4n<NS>(acc[p], im);
       char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
-      *reinterpret_cast<bf16x4 *>(a) = h4;
-      *reinterpret_cast<bf16x4 *>(a + kAImg) = l4;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
     }
   };
 
@@ -333,11 +330,11 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         for (int u = 0; u < 4; ++u)
           a4 = __builtin_elementwise_fma(float4_t{w4[u], w4[u], w4[u], w4[u]}, vv[u], a4);
       }
-      bf16x4 h4, q4;
-      split4(a4, h4, q4);
+      bf16x4 im[NS];
+      split4n<NS>(a4, im);
       char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
-      *reinterpret_cast<bf16x4 *>(a) = h4;
-      *reinterpret_cast<bf16x4 *>(a + kAImg) = q4;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
     }
   };
 
@@ -386,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   for (int s0 = 0; s0 <= D; ++s0) issue(tile_of(s0 / NC), s0 % NC, s0 % NSTG, (s0 / NC) % 3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if constexpr (K8_ROLES != 0 && !DENSE && D == 1) aggregate_lean(0, 0, 0);
+  if constexpr (ROLES) aggregate_lean(0, 0, 0);
   else aggregate(0, 0, 0);
 
   // ---- steady state: interval s = i NC + c ---------------------------------------------------------------
@@ -482,21 +479,21 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           for (int u = 0; u < 4; ++u)
             acc = __builtin_elementwise_fma(float4_t{w4[u], w4[u], w4[u], w4[u]}, v[u], acc);
         } else if (j == 3) {
-          bf16x4 h4, l4;
-          split4(acc, h4, l4);
+          bf16x4 im[NS];
+          split4n<NS>(acc, im);
           char *a = lds + kOffA + ab1 * kABytes + (lr * kPB + mi * 4) * 2;
-          *reinterpret_cast<bf16x4 *>(a) = h4;
-          *reinterpret_cast<bf16x4 *>(a + kAImg) = l4;
+#pragma unroll
+          for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
         }
       };
       const char *abase = lds + kOffA + (s & 1) * kABytes;
-      bf16x8 afrag[2];                                    // A fragments (hi, lo) of the unit about to run
+      bf16x8 afrag[NS];                                   // A fragments (NS images) of the unit about to run
       {
         const char *ap = abase + ((tt0 * 16 + mi) * kPB + 8 * mh) * 2;
-        afrag[0] = *reinterpret_cast<const bf16x8 *>(ap);
-        afrag[1] = *reinterpret_cast<const bf16x8 *>(ap + kAImg);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
       }
-      if constexpr (K8_ROLES != 0 && !DENSE && D == 1) {
+      if constexpr (ROLES) {
         // ---- ROLES: every DMA of chunk s+2 first, then the step's two halves -- X = aggregate(s+1) (LDS reads,
         // VALU) and Y = mfma(s) (matrix pipe) -- in OPPOSITE order on the two waves of a SIMD (waves w, w + NW/2),
         // so that one wave's matrix work runs beside the other's vector work instead of both weaving the same
@@ -533,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
                   for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
                 }
-                if (K8_NT) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
+                if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
                 d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
               }
@@ -543,19 +540,17 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           gwen_static_for<NU>([&](auto uu) {
             constexpr int u = decltype(uu)::value;
             constexpr int ti = u >> 1, k2 = u & 1, ks = 2 * c + k2;
-            const bf16x8 ahi = afrag[0], alo = afrag[1];
+            bf16x8 acur[NS];
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) acur[s_] = afrag[s_];
             if constexpr (u + 1 < NU) {
               constexpr int tn = (u + 1) >> 1, kn = (u + 1) & 1;
               const char *ap = abase + (((tt0 + tn * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + kn * 64;
-              afrag[0] = *reinterpret_cast<const bf16x8 *>(ap);
-              afrag[1] = *reinterpret_cast<const bf16x8 *>(ap + kAImg);
+#pragma unroll
+              for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
             }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], alo, d[ct][ti], 0, 0, 0);
-              d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ct][ks], ahi, d[ct][ti], 0, 0, 0);
-              d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], ahi, d[ct][ti], 0, 0, 0);
-            }
+            for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, d[ct][ti]);
           });
           if (K8_PRIO) __builtin_amdgcn_s_setprio(0);
         };
@@ -621,7 +616,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
                   for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
                 }
-                if (K8_NT) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
+                if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
                 d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
               }
@@ -637,25 +632,23 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           // the unit's A fragments were read one region earlier (their LDS latency sits behind that region's
           // MFMAs); the next unit's are requested now
           constexpr int ti = u >> 1, k2 = u & 1, ks = 2 * c + k2;
-          const bf16x8 ahi = afrag[0], alo = afrag[1];
+          bf16x8 acur[NS];
+#pragma unroll
+          for (int s_ = 0; s_ < NS; ++s_) acur[s_] = afrag[s_];
           if constexpr (u + 1 < NU) {
             constexpr int tn = (u + 1) >> 1, kn = (u + 1) & 1;
             const char *ap = abase + (((tt0 + tn * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + kn * 64;
-            afrag[0] = *reinterpret_cast<const bf16x8 *>(ap);
-            afrag[1] = *reinterpret_cast<const bf16x8 *>(ap + kAImg);
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
           }
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], alo, d[ct][ti], 0, 0, 0);
-            d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[ct][ks], ahi, d[ct][ti], 0, 0, 0);
-            d[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[ct][ks], ahi, d[ct][ti], 0, 0, 0);
-          }
+          for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, d[ct][ti]);
         }
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k)
           if (k * NU / NSTAGE == u) stage_valu(k);
 #pragma unroll
-        for (int k = 0; k < CT * 3; ++k) {
+        for (int k = 0; k < CT * (NS == 2 ? 3 : 6); ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, WEAVE_VALU, 0);     // a few VALU instructions behind it
         }
@@ -672,7 +665,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
 }
 
-template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false>
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false, int NS = 2>
 int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st, int64_t ldx = FIN) {
@@ -686,8 +679,13 @@ int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, con
   const int64_t T = (N + kRows - 1) / kRows, G = T * members;
   if (G >= (int64_t(1) << 31)) return GWEN_ERANGE;
   const int64_t blocks = G < cus ? G : cus;
-  k_wide<FIN, FOUT, NW, D, KU, EARLY, DENSE><<<(unsigned)blocks, NW * 64, 0, st>>>(
-      t_rows, t_lid, t_val, x, W, bias, out, (int32_t)N, (int32_t)T, (int32_t)G, ldo, msx, mso, relu, (int32_t)ldx);
+  // output rows nobody re-reads before they leave the 256 MiB Infinity Cache anyway (in + out beyond it) are stored
+  // non-temporally: they then do not push the halo rows the tiles share out of the caches (64 channels x 16
+  // members: 204 -> 191 us per layer in the 4-layer stack); a working set that fits stays on plain stores (the
+  // next layer reads its input from the cache: 256 channels x 1 member 69.7 vs 74.3 us with nt)
+  const int nt = K8_NT >= 0 ? K8_NT : (members * N * (int64_t)(FIN + FOUT) * 4 > (int64_t(300) << 20) ? 1 : 0);
+  k_wide<FIN, FOUT, NW, D, KU, EARLY, DENSE, NS><<<(unsigned)blocks, NW * 64, 0, st>>>(
+      t_rows, t_lid, t_val, x, W, bias, out, (int32_t)N, (int32_t)T, (int32_t)G, ldo, msx, mso, relu, (int32_t)ldx, nt);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
@@ -698,14 +696,21 @@ constexpr bool fout_ok(int64_t f) { return f == 64 || f == 128 || f == 256; }
 }  // namespace
 
 // K3's tall case on the K8 pipeline: h[rows, Fout] = act(x[rows, Fin (pitch ldx)] W^T + b).  Internal: called by
-// gwen_gcn_linear_f32 (linear.hip), which has validated the pointers.
+// gwen_gcn_linear_f32 (linear.hip), which has validated the pointers.  contract: bf16x3, or bf16x6 up to Fin = 128.
 int gwen_wide_dense_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows, int64_t Fin,
-                        int64_t Fout, int64_t ldx, int64_t ldh, int relu, hipStream_t st) {
+                        int64_t Fout, int64_t ldx, int64_t ldh, int relu, int contract, hipStream_t st) {
   if (!fin_ok(Fin) || !fout_ok(Fout) || rows * ldx * 4 >= (int64_t(1) << 32) || rows >= (int64_t(1) << 31) - 64)
     return GWEN_ERANGE;
+  const bool x6 = contract == GWEN_CONTRACT_BF16X6;
+  if (x6 && Fin > 128) return GWEN_ERANGE;
 #define GWEN_D(FI, FO)                                                                                  \
   if (Fin == FI && Fout == FO) {                                                                        \
     constexpr int NWV = FI >= 256 ? 8 : 16;                                                             \
+    if constexpr (FI <= 128) {                                                                          \
+      if (x6)                                                                                           \
+        return launch<FI, FO, NWV, 2, 64, true, true, 3>(nullptr, nullptr, nullptr, x, W, bias, h, rows, ldh, \
+                                                         1, 0, 0, relu, st, ldx);                       \
+    }                                                                                                   \
     return launch<FI, FO, NWV, 2, 64, true, true>(nullptr, nullptr, nullptr, x, W, bias, h, rows, ldh,  \
                                                   1, 0, 0, relu, st, ldx);                              \
   }
@@ -720,6 +725,12 @@ extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
   return fin_ok(Fin) && fout_ok(Fout) ? 1 : 0;
 }
 
+extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract) {
+  if (!gwen_gcn_wide_supported(Fin, Fout)) return 0;
+  if (contract == GWEN_CONTRACT_BF16X3) return 1;
+  return contract == GWEN_CONTRACT_BF16X6 && Fin <= 128 ? 1 : 0;   // three images of W: 192 registers at Fin = 256
+}
+
 extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
   if (!gwen_gcn_wide_supported(Fin, Fout) || N <= 0 || members <= 0) return 0;
   return Fin >= 128 || N * members >= 300000 ? 1 : 0;
@@ -730,10 +741,10 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
                                        const float *bias, float *out, int64_t N, int64_t N_src,
                                        int64_t Fin, int64_t Fout, int64_t ldo, int64_t members,
                                        int64_t mstride_x, int64_t mstride_o, int relu,
-                                       int64_t union_max, gwen_stream_t stream_) {
+                                       int64_t union_max, int contract, gwen_stream_t stream_) {
   if (N < 0 || N_src < 0 || members < 0 || ldo < Fout || union_max < 0 || union_max > kUCap)
     return GWEN_EINVAL;
-  if (!gwen_gcn_wide_supported(Fin, Fout)) return GWEN_EINVAL;
+  if (!gwen_gcn_wide_contract_supported(Fin, Fout, contract)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
   if (!t_rows || !t_lid || !t_val || !x || !W || !out || x == out) return GWEN_EINVAL;
   if (!gwen_aligned(x, 16) || !gwen_aligned(out, 16) || !gwen_aligned(W, 16) || mstride_x % 4 ||
@@ -742,18 +753,24 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
     return GWEN_EINVAL;
   if (N_src * Fin * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;     // 32-bit row offsets
   hipStream_t st = gwen_stream(stream_);
-  // unions of at most 128 rows leave room for a third stage buffer: two chunks of DMA in flight.
   // 16 waves where the registers allow (Fin <= 128), 8 at Fin = 256 (W alone is 128 registers there).
   // One chunk of DMA in flight behind the chunk being aggregated (D = 1), issued in the first regions of a
   // step.  A CU takes ~32 LDS-DMA wave instructions in flight before further issues stall (measured,
   // tools/experiments/reads/glds.hip: 65 cycles per issue up to 32 outstanding, 200-500 beyond), so a second
   // chunk in flight (D = 2, which unions <= 128 rows would leave LDS room for) only moves the wait into the
   // issue: 246-252 us either way at 256 channels x 4 members.  Unions <= 128 rows stage 128 slots per chunk.
+  // bf16x6 keeps a third image of every A chunk: its LDS fits beside 128-slot stage buffers only, so unions
+  // beyond 128 rows are refused (GWEN_ERANGE: the caller takes K4).
   const bool small_union = union_max <= 128;
+  const bool x6 = contract == GWEN_CONTRACT_BF16X6;
+  if (x6 && !small_union) return GWEN_ERANGE;
 #define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
 #define GWEN_W(FI, FO)                                                                                \
   if (Fin == FI && Fout == FO) {                                                                      \
     constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
+    if constexpr (FI <= 128) {                                                                        \
+      if (x6) return launch<FI, FO, NWV, 1, 128, true, false, 3>(GWEN_ARGS);                          \
+    }                                                                                                 \
     return small_union ? launch<FI, FO, NWV, 1, 128, true>(GWEN_ARGS)                                 \
                        : launch<FI, FO, NWV, 1, 192, true>(GWEN_ARGS);                                \
   }

@@ -97,9 +97,10 @@ class InteractionForecaster(nn.Module):
 
     @staticmethod
     def _lin(x: Tensor, m: nn.Linear) -> Tensor:
-        """K3 for inference; torch's own linear (library GEMM, differentiable) when gradients are needed."""
+        """K3 (bf16x3, as the blocks around it); with autograd when gradients are needed (ops.LinearFunction:
+        the backward runs on K3 and the gradient reductions too)."""
         if torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad):
-            return nn.functional.linear(x, m.weight, m.bias)
+            return ops.linear_autograd(x, m.weight, m.bias, contract="3xbf16")
         return ops.linear(x, m.weight, m.bias, exact=False)
 
     def _static(self, graphs: ForecastGraphs):

@@ -15,9 +15,14 @@ from torch import Tensor
 from . import _lib
 from .graph import GraphCSR, _ptr, _stream
 
-_ORDERS = {"auto": _lib.ORDER_AUTO, "transform_first": _lib.ORDER_TRANSFORM_FIRST,
-           "aggregate_first": _lib.ORDER_AGGREGATE_FIRST, "fused": _lib.ORDER_FUSED,
-           "fused_exact": _lib.ORDER_FUSED_EXACT}
+# order string -> (GWEN_ORDER_*, GWEN_CONTRACT_* of an AUTO / FUSED layer).  "auto" / "fused" contract on the
+# fp32-class bf16x6 split (the default precision), "auto_x3" / "fused_x3" on the faster bf16x3 split; the
+# explicit two-launch orders and "fused_exact" use the fp32-input MFMA whatever the second entry says.
+_ORDERS = {"auto": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X6), "auto_x3": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X3),
+           "transform_first": (_lib.ORDER_TRANSFORM_FIRST, _lib.CONTRACT_BF16X6),
+           "aggregate_first": (_lib.ORDER_AGGREGATE_FIRST, _lib.CONTRACT_BF16X6),
+           "fused": (_lib.ORDER_FUSED, _lib.CONTRACT_BF16X6), "fused_x3": (_lib.ORDER_FUSED, _lib.CONTRACT_BF16X3),
+           "fused_exact": (_lib.ORDER_FUSED_EXACT, _lib.CONTRACT_BF16X6)}
 
 
 class KernelEvents:
@@ -125,7 +130,8 @@ class StackForward:
             d = self.desc[i]
             d.W, d.bias = w.data_ptr(), (0 if b is None else b.data_ptr())
             d.fout, d.fin = w.size(0), w.size(1)
-            d.relu, d.order = int(relu), _ORDERS[order]
+            d.relu = int(relu)
+            d.order, d.contract = _ORDERS[order]
             img = None if packed is None else packed[i]
             d.packed = 0 if img is None else img.data_ptr()
             self._keep.append(img)
@@ -134,7 +140,8 @@ class StackForward:
         # when it holds the grouped layout is never read, so it is not built (a kernel and a read-back
         # per fresh graph -- the reference's loaders hand over a new edge_index per batch)
         self._small = graph.dense() is not None and all(
-            d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, d.fin, d.fout)
+            d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, d.fin, d.fout,
+                                                                               d.contract)
             for d in self.desc)
         # long rows beyond K7's graphs: per-layer K3 + segmented K2 (ops.propagate) instead of the C launcher,
         # whose fused kernels walk a row serially
@@ -162,6 +169,7 @@ class StackForward:
         g = self.graph
         want_tiles = (not self._small) and any(
             d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_wide_preferred(g.num_nodes, members, d.fin, d.fout)
+            and _lib.lib().gwen_gcn_wide_contract_supported(d.fin, d.fout, d.contract)
             for d in self.desc)
         key = (members if want_tiles else 0, want_tiles)
         if self._gd_key != key:
@@ -203,12 +211,12 @@ class StackForward:
             from . import ops
             cur = x
             for i, (w, b, relu, order) in enumerate(self._layers):
-                exact = order != "auto"
+                contract = ops.contract_of_order(order)
                 if w.size(1) < w.size(0):                      # gather at the narrower width
                     cur = ops.linear(ops.propagate(self.graph, cur), w.detach(), None if b is None else b.detach(),
-                                     relu, exact=exact)
+                                     relu, contract=contract)
                 else:
-                    cur = ops.propagate(self.graph, ops.linear(cur, w.detach(), exact=exact),
+                    cur = ops.propagate(self.graph, ops.linear(cur, w.detach(), contract=contract),
                                         None if b is None else b.detach(), relu)
                 if acts is not None:
                     acts[i].copy_(cur)

@@ -8,7 +8,8 @@ oracle/interaction_oracle.py, PARITY UNPINNED):
     agg_d = sum / mean of m_e over the in-edges of d
     x'_d  = x_dst_d + MLP_n([x_dst_d, agg_d]) ,   e' = e + m_e
 
-How it runs (3 launches on a square graph, 4 on a bipartite one; training: _InteractionNetFunction):
+How it runs (3 launches on a square graph, 4 on a bipartite one; training: _InteractionNetFunction, whose backward
+is assembled from atomic-free launches of libgwen_hip.so as well -- csrc/interact_bwd.hip):
   * the node halves of both first layers are projected per NODE, not per edge, by ONE K3 launch with the
     three weights stacked (3xbf16): [Ps | Pd | Q] = x [W1[:, F:2F]; W1[:, 2F:]; W3[:, :F]]^T + [0, b1, b3]
     (sources projected apart when x_src is not x_dst); K6 reads them as strided column blocks;
@@ -46,6 +47,37 @@ class EdgeGraph:
     max_degree: int       # longest target row
     _tiles: Dict[int, Tuple[Tensor, int]] = field(default_factory=dict, repr=False)
     _batched: Dict[int, "EdgeGraph"] = field(default_factory=dict, repr=False)
+    _seg: Dict[str, tuple] = field(default_factory=dict, repr=False)
+
+    def segments(self, by: str, mean: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+        """CSR (rowptr, col, val) whose columns are stored-EDGE positions: K2 over it sums, per target
+        (``by="dst"``) or per source (``by="src"``) node, rows of an [E, F] array in stored order -- the
+        atomic-free form of the backward's scatter-adds.  ``mean``: 1/in-degree weights (targets only).
+        Index plumbing, built once per graph."""
+        key = by + ("_mean" if mean else "")
+        if key not in self._seg:
+            dev, e = self.device, self.num_edges
+            ones = torch.ones(max(e, 1), dtype=torch.float32, device=dev)[:e]
+            if by == "dst":
+                col = torch.arange(e, dtype=torch.int32, device=dev)
+                val = self.inv_degree().index_select(0, self.dst.long()) if mean else ones
+                self._seg[key] = (self.rowptr, col, val.contiguous())
+            elif by == "src" and not mean:
+                order = torch.sort(self.src.long(), stable=True).indices        # stored order inside a source's run
+                counts = torch.bincount(self.src.long(), minlength=self.num_src)
+                rowptr = torch.zeros(self.num_src + 1, dtype=torch.int32, device=dev)
+                rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+                self._seg[key] = (rowptr, order.to(torch.int32).contiguous(), ones)
+            else:
+                raise ValueError("segments: by in ('dst', 'src'); mean only by 'dst'")
+        return self._seg[key]
+
+    def inv_degree(self) -> Tensor:
+        """1 / max(in-degree, 1) per target node, fp32 [num_dst] (mean aggregation)."""
+        if "inv_deg" not in self._seg:
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32).clamp(min=1.0)
+            self._seg["inv_deg"] = (1.0 / deg).contiguous()
+        return self._seg["inv_deg"]
 
     @property
     def device(self) -> torch.device:
@@ -176,7 +208,7 @@ def _mlp(fin: int, f: int, act: str) -> nn.Sequential:
 class InteractionNet(nn.Module):
     """``forward(x_src, x_dst, e, graph) -> (x_dst', e')``; parameters ``edge_mlp.{0,2}.{weight,bias}``
     ([F,3F] / [F,F]) and ``node_mlp.{0,2}.{weight,bias}`` ([F,2F] / [F,F]).  Forward on K6; when gradients are
-    needed the backward recomputes the block in torch device ops (``_InteractionNetFunction``)."""
+    needed the backward runs on libgwen_hip.so as well (``_InteractionNetFunction``: atomic-free, reproducible)."""
 
     def __init__(self, channels: int, activation: str = "silu", aggr: str = "sum"):
         super().__init__()
@@ -237,32 +269,67 @@ class InteractionNet(nn.Module):
                         res=x_dst, act=self.activation)
         return x_new, e_new
 
-    def _forward_torch(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph, params):
-        """The block in differentiable torch device ops (library GEMMs, index_select, index_add_) on the
-        graph's STORED edge order: what the backward pass differentiates (recomputed, see
-        ``_InteractionNetFunction``).  ``params`` in ``self.parameters()`` order."""
-        w1, b1, w2, b2, w3, b3, w4, b4 = params
-        f = self.channels
-        act = {"none": lambda v: v, "relu": torch.relu, "silu": torch.nn.functional.silu}[self.activation]
-        src, dst = graph.src.long(), graph.dst.long()
-        pre = e @ w1[:, :f].t() + (x_src @ w1[:, f:2 * f].t()).index_select(0, src) + \
-            (x_dst @ w1[:, 2 * f:].t() + b1).index_select(0, dst)
-        m = act(pre) @ w2.t() + b2
-        agg = torch.zeros_like(x_dst).index_add_(0, dst, m)
-        if self.aggr == "mean":
-            deg = (graph.rowptr[1:] - graph.rowptr[:-1]).to(m.dtype).clamp(min=1).view(-1, 1)
-            agg = agg / deg
-        x_new = x_dst + act(x_dst @ w3[:, :f].t() + agg @ w3[:, f:].t() + b3) @ w4.t() + b4
-        return x_new, e + m
+
+# ---- pieces of the backward (csrc/interact_bwd.hip + K2 / K3 / the gradient reductions) -------------------------
+_BWD_CONTRACT = "3xbf16"          # the block's forward (K6) contracts on the bf16x3 split; so does its backward
+
+
+def _act_pair(a: Tensor, act: str, g1: Optional[Tensor] = None, idx1: Optional[Tensor] = None,
+              g2: Optional[Tensor] = None, idx2: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """(act(pre), act'(pre)) with pre = a + g1[idx1 or row] + g2[idx2 or row]; act(pre) overwrites ``a``."""
+    rows, f = a.shape
+    d = torch.empty_like(a)
+    dev = a.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_act_pair_f32(_ptr(a), _ptr(g1), _ptr(idx1), 0 if g1 is None else g1.stride(0),
+                                          _ptr(g2), _ptr(idx2), 0 if g2 is None else g2.stride(0), _ptr(a),
+                                          _ptr(d), rows, f, _ACT[act], _stream(dev))
+    _lib.check(rc, "gwen_act_pair_f32")
+    return a, d
+
+
+def _gather_add(a: Optional[Tensor], t: Tensor, idx: Tensor, scale: Optional[Tensor] = None) -> Tensor:
+    rows, f = idx.numel(), t.size(-1)
+    out = torch.empty(rows, f, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        rc = _lib.lib().gwen_gather_add_f32(_ptr(a), _ptr(t), _ptr(idx), _ptr(scale), _ptr(out), rows, f,
+                                            _stream(t.device))
+    _lib.check(rc, "gwen_gather_add_f32")
+    return out
+
+
+def _ew(op: int, a: Tensor, b: Tensor) -> Tensor:
+    """a * b or a + b, written over ``a``."""
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().gwen_ew_f32(op, _ptr(a), _ptr(b), _ptr(a), a.numel(), _stream(a.device))
+    _lib.check(rc, "gwen_ew_f32")
+    return a
+
+
+def _segsum(seg: Tuple[Tensor, Tensor, Tensor], h: Tensor, rows: int) -> Tensor:
+    """K2 over an edge-position CSR (``EdgeGraph.segments``): out[i] = sum_s val[s] h[col[s]] in stored order."""
+    rowptr, col, val = seg
+    f = h.size(-1)
+    out = torch.empty(rows, f, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        rc = _lib.lib().gwen_gcn_propagate_f32(_ptr(rowptr), _ptr(col), _ptr(val), _ptr(h), None, _ptr(out), rows, f,
+                                               f, f, 1, h.numel(), rows * f, 0, _stream(h.device))
+    _lib.check(rc, "gwen_gcn_propagate_f32")
+    return out
 
 
 class _InteractionNetFunction(torch.autograd.Function):
-    """Training through an InteractionNet block: the forward runs on K6 (no intermediate is kept), the
-    backward RECOMPUTES the block in torch device ops under autograd (``InteractionNet._forward_torch``:
-    rocBLAS GEMMs, index_select, index_add_) and differentiates that.  A correctness-first path for the
-    BUILD-DEFINED f2 models (the reference has no edge MLP): no hand-written backward kernels yet, the
-    scatter-adds of the backward use float atomics (not bitwise reproducible), and the recomputation costs
-    one extra forward in library kernels."""
+    """Training through an InteractionNet block, forward AND backward on libgwen_hip.so.  The forward runs on K6 and
+    keeps no intermediate; the backward recomputes the two hidden layers (K3 + ``gwen_act_pair_f32``, which also
+    yields the activation's derivative) and then walks the block in reverse:
+        node MLP:  g_pre3 = (gx W4) * act'(pre3);   g_agg = g_pre3 Wa;   g_x += gx + g_pre3 Wx
+        messages:  g_m[e] = ge[e] + g_agg[dst(e)] (/ degree for the mean)          (``gwen_gather_add_f32``)
+        edge MLP:  g_pre1 = (g_m W2) * act'(pre1);  g_e = ge + g_pre1 We
+        nodes:     G_d = sum of g_pre1 over a target's edges, G_s over a source's   (K2 over ``EdgeGraph.segments``:
+                   stored order, no atomics);  g_x_dst += G_d Wd,  g_x_src = G_s Ws
+        weights:   every grad_W = (gradient rows)^T (input rows), grad_b = column sums   (fixed-order reductions)
+    Every launch is atomic-free with a fixed summation order: two backward runs are bitwise equal.  BUILD-DEFINED
+    like the block (the reference has no edge MLP); gradients are tested against fp64 autograd of the oracle."""
 
     @staticmethod
     def forward(ctx, net, graph, update_edges, same, x_src, x_dst, e, *params):
@@ -277,25 +344,57 @@ class _InteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gx, ge):
-        x_src, x_dst, e, *params = ctx.saved_tensors
-        need = ctx.needs_input_grad[4:]
-        with torch.enable_grad():
-            xd = x_dst.detach().requires_grad_(need[1] or (ctx.same and need[0]))
-            xs = xd if ctx.same else x_src.detach().requires_grad_(need[0])
-            ee = e.detach().requires_grad_(need[2])
-            ps = [p.detach().requires_grad_(n) for p, n in zip(params, need[3:])]
-            x_new, e_new = ctx.net._forward_torch(xs, xd, ee, ctx.graph, ps)
-            outs, gouts = [x_new], [gx]
-            if ctx.update_edges and ge is not None:
-                outs.append(e_new); gouts.append(ge)
-            wanted = [t for t in ([xd] if ctx.same else [xs, xd]) + [ee] + ps if t.requires_grad]
-            grads = torch.autograd.grad(outs, wanted, gouts, allow_unused=True) if wanted else []
-        it = iter(grads)
-        take = lambda t: next(it) if t.requires_grad else None          # noqa: E731
-        if ctx.same:           # x_src is x_dst: one tensor in two argument slots -- its gradient is reported once
-            g_xs, g_xd = None, take(xd)
-        else:
-            g_xs, g_xd = take(xs), take(xd)
-        g_e = take(ee)
-        g_ps = [take(p) for p in ps]
-        return (None, None, None, None, g_xs, g_xd, g_e, *g_ps)
+        x_src, x_dst, e, w1, b1, w2, b2, w3, b3, w4, b4 = ctx.saved_tensors
+        net, g, same = ctx.net, ctx.graph, ctx.same
+        f, act, mean = net.channels, net.activation, net.aggr == "mean"
+        n_src, n_dst = g.num_src, g.num_dst
+        with torch.no_grad():
+            lin = lambda x, w, b=None: ops.linear(x, w, b, contract=_BWD_CONTRACT)          # noqa: E731
+            tr = lambda w: w.t().contiguous()                                               # noqa: E731
+            x_src, x_dst, e = x_src.detach().contiguous(), x_dst.detach().contiguous(), e.detach().contiguous()
+            gx = gx.contiguous()
+            has_ge = bool(ctx.update_edges and ge is not None and ge.numel() > 0)
+            ge = ge.contiguous() if has_ge else None
+            we, wa = w1[:, :f].contiguous(), w3[:, f:].contiguous()
+            ws_, wd_, wx_ = w1[:, f:2 * f].contiguous(), w1[:, 2 * f:].contiguous(), w3[:, :f].contiguous()
+            # ---- the two hidden layers again (the forward kept nothing) -----------------------------------------
+            ps = lin(x_src, ws_)
+            pd = lin(x_dst, wd_, b1)
+            h1, d1 = _act_pair(lin(e, we), act, ps, g.src, pd, g.dst)
+            del ps, pd
+            m = lin(h1, w2, b2)
+            agg = _segsum(g.segments("dst", mean), m, n_dst)
+            del m
+            h3, d3 = _act_pair(lin(agg, wa), act, lin(x_dst, wx_, b3))
+            # ---- node MLP -----------------------------------------------------------------------------------------
+            g_b4, g_w4 = ops.grad_bias(gx), ops.grad_weight(gx, h3)
+            g_pre3 = _ew(_lib.EW_MUL, lin(gx, tr(w4)), d3)
+            del h3, d3
+            g_b3 = ops.grad_bias(g_pre3)
+            g_w3 = torch.cat([ops.grad_weight(g_pre3, x_dst), ops.grad_weight(g_pre3, agg)], dim=1)
+            g_agg = lin(g_pre3, tr(wa))
+            g_xd = _ew(_lib.EW_ADD, lin(g_pre3, tr(wx_)), gx)
+            del g_pre3, agg
+            # ---- messages and edge MLP ----------------------------------------------------------------------------
+            g_m = _gather_add(ge, g_agg, g.dst, g.inv_degree() if mean else None)
+            g_b2, g_w2 = ops.grad_bias(g_m), ops.grad_weight(g_m, h1)
+            g_pre1 = _ew(_lib.EW_MUL, lin(g_m, tr(w2)), d1)
+            del g_m, h1, d1, g_agg
+            g_b1 = ops.grad_bias(g_pre1)
+            big_d = _segsum(g.segments("dst"), g_pre1, n_dst)          # per target: sum over its in-edges
+            big_s = _segsum(g.segments("src"), g_pre1, n_src)          # per source: sum over its out-edges
+            g_w1 = torch.cat([ops.grad_weight(g_pre1, e), ops.grad_weight(big_s, x_src),
+                              ops.grad_weight(big_d, x_dst)], dim=1)
+            g_e = lin(g_pre1, tr(we))
+            if has_ge:
+                g_e = _ew(_lib.EW_ADD, g_e, ge)
+            del g_pre1
+            g_xs = lin(big_s, tr(ws_))
+            g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, tr(wd_)))
+            if same:           # x_src is x_dst: one tensor in two argument slots -- its gradient is reported once
+                g_xd = _ew(_lib.EW_ADD, g_xd, g_xs)
+                g_xs = None
+        need = ctx.needs_input_grad
+        pick = lambda k, t: t if need[k] else None                                          # noqa: E731
+        return (None, None, None, None, pick(4, g_xs), pick(5, g_xd), pick(6, g_e), pick(7, g_w1), pick(8, g_b1),
+                pick(9, g_w2), pick(10, g_b2), pick(11, g_w3), pick(12, g_b3), pick(13, g_w4), pick(14, g_b4))

@@ -172,13 +172,13 @@ class GNNModel(nn.Module):
             key = (w.data_ptr(), w._version, tuple(w.shape))
             hit = self._packed.get(i)
             if hit is None or hit[0] != key:
-                hit = (key, pack_weight(w) if order == "auto" else None)
+                hit = (key, pack_weight(w) if order == "auto_x3" else None)     # the packed images are 3xbf16's
                 self._packed[i] = hit
             out.append(hit[1])
         return out
 
     def set_precision(self, precision: str) -> "GNNModel":
-        """"3xbf16" (default) or "fp32" for every layer (``GCNConv.precision``); returns self."""
+        """"bf16x6" (default), "3xbf16" or "fp32" for every layer (``GCNConv.precision``); returns self."""
         for mod in self.modules():
             if isinstance(mod, GCNConv):
                 mod.precision = precision

@@ -31,6 +31,27 @@ def _rows2d(x: Tensor):
     raise ValueError(f"expected [N, F] or [members, N, F], got {tuple(x.shape)}")
 
 
+AUTO_ORDERS = ("auto", "auto_x3")
+
+
+def contract_of_order(order: str) -> str:
+    """Contraction of a layer run under ``order``: "auto" / "fused" -> "bf16x6" (the default, fp32-class),
+    "auto_x3" / "fused_x3" -> "3xbf16", every other (explicit) order -> "fp32"."""
+    if order in ("auto", "fused"):
+        return "bf16x6"
+    if order in ("auto_x3", "fused_x3"):
+        return "3xbf16"
+    return "fp32"
+
+
+def _contract_code(contract, exact: bool = True) -> int:
+    if contract is None:
+        return _lib.CONTRACT_F32 if exact else _lib.CONTRACT_BF16X3
+    if contract not in _lib.CONTRACT_NAMES:
+        raise ValueError(f'contract must be one of {sorted(_lib.CONTRACT_NAMES)}')
+    return _lib.CONTRACT_NAMES[contract]
+
+
 def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
               transposed: bool = False) -> Tensor:
     """K2: out[i] = act(sum_s val[s] * h[col[s]] + bias) over the CSR (or its transpose)."""
@@ -67,10 +88,10 @@ def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: b
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
-           exact: bool = True) -> Tensor:
-    """K3: act(x @ weight^T + bias); x [..., Fin], weight [Fout, Fin].  ``exact=True``: fp32-input MFMA
-    (a k-ordered fp32 fmaf chain, the default of the per-layer/autograd path); ``exact=False``: 3xbf16
-    split contraction with fp32 accumulation (what the stack launcher uses for AUTO layers)."""
+           exact: bool = True, contract: Optional[str] = None) -> Tensor:
+    """K3: act(x @ weight^T + bias); x [..., Fin], weight [Fout, Fin].  ``contract``: "fp32" (fp32-input MFMA, a
+    k-ordered fp32 fmaf chain), "bf16x6" (fp32-class split, what AUTO layers use) or "3xbf16" (the faster
+    split); when None, ``exact`` picks between "fp32" (True) and "3xbf16" (False)."""
     _require(x, "x")
     _require(weight, "weight")
     x = x.contiguous()
@@ -84,16 +105,46 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool 
         _require(bias, "bias")
         bias = bias.contiguous()
     dev = x.device
+    code = _contract_code(contract, exact)
     ws = None
-    nws = 0 if exact else int(_lib.lib().gwen_gcn_linear_workspace_floats(rows, fin, fout))
+    nws = 0 if code == _lib.CONTRACT_F32 else int(_lib.lib().gwen_gcn_linear_workspace_floats(rows, fin, fout))
     if nws > 0:
         ws = torch.empty(nws, dtype=torch.float32, device=dev)          # split-K partial products
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_linear_f32(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), rows, fin,
-                                            fout, fin, fout, int(relu), int(exact), _ptr(ws), nws,
+                                            fout, fin, fout, int(relu), code, _ptr(ws), nws,
                                             _stream(dev))
     _lib.check(rc, "gwen_gcn_linear_f32")
     return out
+
+
+class LinearFunction(torch.autograd.Function):
+    """Differentiable K3: y = act(x W^T + b) with the backward on the same library -- g_x = g W (K3), g_W = g^T x and
+    g_b = column sums of g (the fixed-order reductions of K4's backward).  ``act``: "none" or "relu"."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, contract: str) -> Tensor:
+        y = linear(x, weight, bias, relu, contract=contract)
+        ctx.relu, ctx.contract, ctx.has_bias = relu, contract, bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, weight, y = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            g = relu_backward(y, g)
+        gx = linear(g, weight.t().contiguous(), contract=ctx.contract) if ctx.needs_input_grad[0] else None
+        gw = grad_weight(g, x) if ctx.needs_input_grad[1] else None
+        gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None
+
+
+def linear_autograd(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+                    contract: str = "bf16x6") -> Tensor:
+    """K3 with autograd (``LinearFunction``)."""
+    return LinearFunction.apply(x, weight, bias, relu, contract)
 
 
 def layer_supported(fin: int, fout: int) -> bool:
@@ -101,9 +152,9 @@ def layer_supported(fin: int, fout: int) -> bool:
 
 
 def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-                relu: bool = False, exact: bool = False) -> Tensor:
-    """K4: act((A~ x) W^T + b) in one launch (widths in {16,32,64,128}).  ``exact=False``: 3xbf16 split
-    contraction with fp32 accumulation (default); ``exact=True``: fp32-input MFMA."""
+                relu: bool = False, exact: bool = False, contract: Optional[str] = None) -> Tensor:
+    """K4: act((A~ x) W^T + b) in one launch (widths in {16,32,64,128,256}).  ``contract``: "bf16x6", "3xbf16" or
+    "fp32"; when None, ``exact`` picks between "fp32" (True) and "3xbf16" (False)."""
     _require(x, "x")
     _require(weight, "weight")
     x = x.contiguous()
@@ -124,8 +175,8 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_layer_f32(
             _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(weight), _ptr(bias),
-            _ptr(out), n, fin, fout, fin, fout, m, n_src * fin, n * fout, int(relu), int(exact),
-            _stream(dev))
+            _ptr(out), n, fin, fout, fin, fout, m, n_src * fin, n * fout, int(relu),
+            _contract_code(contract, exact), _stream(dev))
     _lib.check(rc, "gwen_gcn_layer_f32")
     return out
 
@@ -134,18 +185,22 @@ def wide_supported(fin: int, fout: int) -> bool:
     return bool(_lib.lib().gwen_gcn_wide_supported(fin, fout))
 
 
-def wide_preferred(graph: GraphCSR, x: Tensor, fin: int, fout: int) -> bool:
+def wide_preferred(graph: GraphCSR, x: Tensor, fin: int, fout: int, contract: str = "3xbf16") -> bool:
     """Would the stack launcher run this AUTO layer as K8?  (Same rule, so training and inference agree.)"""
     m, n_src, _ = _rows2d(x)
-    if not _lib.lib().gwen_gcn_wide_preferred(graph.num_nodes, m, fin, fout):
+    code = _contract_code(contract)
+    if not _lib.lib().gwen_gcn_wide_preferred(graph.num_nodes, m, fin, fout) or \
+            not _lib.lib().gwen_gcn_wide_contract_supported(fin, fout, code):
         return False
-    return graph.tiles() is not None
+    tiles = graph.tiles()
+    return tiles is not None and (code == _lib.CONTRACT_BF16X3 or tiles[3] <= 128)
 
 
 def wide_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-               relu: bool = False) -> Tensor:
+               relu: bool = False, contract: str = "3xbf16") -> Tensor:
     """K8: act((A~ x) W^T + b) in one launch, tile-staged through LDS (widths in {64,128,256}, graphs
-    that tile: ``graph.tiles()``).  3xbf16 contraction; term for term K4's arithmetic."""
+    that tile: ``graph.tiles()``).  ``contract``: "3xbf16", or "bf16x6" for Fin <= 128 on graphs whose tile
+    unions stay within 128 rows; term for term K4's arithmetic."""
     _require(x, "x")
     _require(weight, "weight")
     x = x.contiguous()
@@ -168,22 +223,25 @@ def wide_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_wide_layer_f32(
             _ptr(t_rows), _ptr(t_lid), _ptr(t_val), _ptr(x), _ptr(weight), _ptr(bias), _ptr(out),
-            n, n_src, fin, fout, fout, m, n_src * fin, n * fout, int(relu), umax, _stream(dev))
+            n, n_src, fin, fout, fout, m, n_src * fin, n * fout, int(relu), umax, _contract_code(contract),
+            _stream(dev))
     _lib.check(rc, "gwen_gcn_wide_layer_f32")
     return out
 
 
 def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-                relu: bool = False, packed: Optional[Tensor] = None) -> Tensor:
+                relu: bool = False, packed: Optional[Tensor] = None, contract: str = "3xbf16") -> Tensor:
     """K7: act(A~ (x W^T) + b) in one launch on a graph of at most 256 nodes (dense adjacency).
-    ``packed``: the weight's ``gwen_amd.forward.pack_weight`` image (streamed instead of ``weight``)."""
+    ``packed``: the weight's ``gwen_amd.forward.pack_weight`` image (streamed instead of ``weight``; "3xbf16"
+    only).  ``contract``: "3xbf16" or "bf16x6"."""
     _require(x, "x")
     _require(weight, "weight")
     x, weight = x.contiguous(), weight.contiguous()
     m, n_src, fin = _rows2d(x)
     n, fout = graph.num_nodes, weight.size(0)
     dense = graph.dense()
-    if dense is None or not _lib.lib().gwen_gcn_small_supported(n, fin, fout):
+    code = _contract_code(contract)
+    if dense is None or not _lib.lib().gwen_gcn_small_supported(n, fin, fout, code):
         raise ValueError("K7 needs a square graph of at most 256 nodes, Fin % 32 == 0, Fout % 16 == 0")
     if n_src != n or weight.size(1) != fin:
         raise ValueError("shape mismatch between x, weight and the graph")
@@ -197,14 +255,15 @@ def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_small_layer_f32(_ptr(dense), _ptr(x), _ptr(weight), _ptr(packed), _ptr(bias), _ptr(out),
                                                  n, fin, fout, m, n * fin, n * fout, int(relu), _ptr(ws),
-                                                 nws, _stream(dev))
+                                                 nws, code, _stream(dev))
     _lib.check(rc, "gwen_gcn_small_layer_f32")
     return out
 
 
 def chain(graph: GraphCSR, x: Tensor, w1: Tensor, w2: Optional[Tensor], bias: Optional[Tensor],
-          relu: bool, pre: bool) -> Tensor:
-    """K5.  pre=False: act((A~ x) w1^T + bias) w2^T;  pre=True: act(A~ x + bias) w1^T  (inference only)."""
+          relu: bool, pre: bool, contract: str = "3xbf16") -> Tensor:
+    """K5.  pre=False: act((A~ x) w1^T + bias) w2^T;  pre=True: act(A~ x + bias) w1^T  (inference only).
+    ``contract``: "3xbf16" or "bf16x6"."""
     _require(x, "x")
     x = x.contiguous()
     m, n, fin = _rows2d(x)
@@ -218,7 +277,8 @@ def chain(graph: GraphCSR, x: Tensor, w1: Tensor, w2: Optional[Tensor], bias: Op
         rc = _lib.lib().gwen_gcn_chain_f32(
             _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(w1.contiguous()),
             None if w2 is None else _ptr(w2.contiguous()), None if bias is None else _ptr(bias.contiguous()),
-            _ptr(out), n, fin, f1, f2, int(pre), int(relu), m, n * fin, n * fw, _stream(dev))
+            _ptr(out), n, fin, f1, f2, int(pre), int(relu), m, n * fin, n * fw, _contract_code(contract),
+            _stream(dev))
     _lib.check(rc, "gwen_gcn_chain_f32")
     return out
 
@@ -281,37 +341,39 @@ class GCNLayerFunction(torch.autograd.Function):
                 relu: bool, order: str, packed: Optional[Tensor] = None) -> Tensor:
         fout, fin = weight.shape
         # one precision rule for both host paths (this Function and the stack launcher, forward.hip): an AUTO
-        # layer contracts with the 3xbf16 split whatever kernels it resolves to; explicit orders
-        # ("transform_first", "aggregate_first", "fused_exact") use the exact fp32-input MFMA
-        exact = order != "auto"
-        if order == "auto":
-            if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout):
+        # layer contracts with its split ("auto": bf16x6, "auto_x3": 3xbf16) whatever kernels it resolves to;
+        # explicit orders ("transform_first", "aggregate_first", "fused_exact") use the exact fp32-input MFMA
+        contract = contract_of_order(order)
+        if order in AUTO_ORDERS:
+            if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout,
+                                                                                 _contract_code(contract)):
                 order = "small"              # K7: the reference's member graphs (<= 256 nodes)
             elif graph.long_row_levels() is not None:
                 # rows far beyond 8 entries: the fused kernels walk a row serially, the segment chain does not
                 order = "aggregate_first" if fin < fout else "transform_first"
-            elif wide_preferred(graph, x, fin, fout):
+            elif wide_preferred(graph, x, fin, fout, contract):
                 order = "wide"               # K8: K4's arithmetic, tile-staged (same backward)
             elif layer_supported(fin, fout):
                 order = "fused"
             else:
                 order = "aggregate_first" if fin < fout else "transform_first"
         if order == "small":
-            out = small_layer(graph, x, weight, bias, relu, packed=packed)
+            out = small_layer(graph, x, weight, bias, relu, packed=packed if contract == "3xbf16" else None,
+                              contract=contract)
             saved_in = x
         elif order == "wide":
-            out = wide_layer(graph, x, weight, bias, relu)
+            out = wide_layer(graph, x, weight, bias, relu, contract=contract)
             saved_in = x
-        elif order in ("fused", "fused_exact"):
-            out = layer_fused(graph, x, weight, bias, relu, exact=(order == "fused_exact"))
+        elif order in ("fused", "fused_x3", "fused_exact"):
+            out = layer_fused(graph, x, weight, bias, relu, contract=contract)
             saved_in = x
         elif order == "transform_first":
-            h = linear(x, weight, exact=exact)
+            h = linear(x, weight, contract=contract)
             out = propagate(graph, h, bias, relu)
             saved_in = x
         elif order == "aggregate_first":
             agg = propagate(graph, x)
-            out = linear(agg, weight, bias, relu, exact=exact)
+            out = linear(agg, weight, bias, relu, contract=contract)
             saved_in = agg
         else:
             raise ValueError(f"unknown order {order!r}")
@@ -327,7 +389,7 @@ class GCNLayerFunction(torch.autograd.Function):
             g = relu_backward(out, g)
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         gx = gw = None
-        if ctx.order in ("transform_first", "fused", "fused_exact", "small", "wide"):       # out = act(A~ x W^T + b) either way
+        if ctx.order in ("transform_first", "fused", "fused_x3", "fused_exact", "small", "wide"):   # out = act(A~ x W^T + b) either way
             gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x

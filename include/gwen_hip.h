@@ -136,11 +136,25 @@ int gwen_gcn_propagate_f32(const int32_t *rowptr, const int32_t *col, const floa
                            int64_t mstride_o, int relu, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Contractions.  The reference's `lin` is an fp32 GEMM (/root/reference/src/gwen/models_gnn.py:118-130 -> PyG
+ * Linear).  Every kernel with a dense contraction (K3, K4, K5, K8) takes one of these codes (the parameter is
+ * called `exact` in K3 / K4 for history, `contract` elsewhere):
+ *   GWEN_CONTRACT_BF16X3 (0)  operands cut into two bf16 images (x = hi + lo), 3 MFMAs per k-step, fp32
+ *                             accumulation: ~17 bits per product, 7e-6 relative on the 6-layer model;
+ *   GWEN_CONTRACT_F32    (1)  fp32-input MFMA: bit-identical to a k-ordered fp32 fmaf chain, 1/16 of the bf16 rate;
+ *   GWEN_CONTRACT_BF16X6 (2)  three bf16 images per operand, 6 MFMAs per k-step: 24 bits per operand, fp32-class
+ *                             (<= 2e-6 on the 6-layer model) at 6/16 of the fp32 MFMA's cost -- the host API's default.
+ * ------------------------------------------------------------------------------------------- */
+#define GWEN_CONTRACT_BF16X3 0
+#define GWEN_CONTRACT_F32 1
+#define GWEN_CONTRACT_BF16X6 2
+
+/* ---------------------------------------------------------------------------------------------
  * K3  dense projection == GCNConv.lin (PyG Linear(Fin, Fout, bias=False)):  h = x @ W^T.
  * x [rows, Fin] (row stride ldx), W [Fout, Fin] contiguous (lin.weight), h [rows, Fout]
  * (row stride ldh).  Optional epilogue: + bias[Fout] (NULL = none), ReLU.
- * exact = 0: 3xbf16 split contraction, fp32 accumulate (as K4; < 2^-15 relative per product);
- * exact = 1: fp32-input MFMA (v_mfma_f32_32x32x2_f32), bit-identical to a k-ordered fp32 fmaf chain.
+ * exact: a GWEN_CONTRACT_* code (0: bf16x3 split, fp32 accumulate, as K4; 1: fp32-input MFMA
+ *   v_mfma_f32_32x32x2_f32, bit-identical to a k-ordered fp32 fmaf chain; 2: bf16x6 split).
  * workspace (optional, gwen_gcn_linear_workspace_floats() elements; 0 = not needed): lets the split
  *   variant cut a long K over several blocks when there are few output tiles (few rows x wide input,
  *   the reference's own C -> 1024 projection on ~125 nodes) and add the partial products in a fixed
@@ -158,7 +172,8 @@ int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float
  * and stores once at width Fout: no [N, Fout] intermediate `h` goes through HBM.
  * exact = 0: the contraction runs as a 3-term bf16 split (x = hi + lo, fp32 accumulate; < 2^-15
  *   relative per product, 8e-6 measured on the 6-layer model against a 1e-4 tolerance);
- * exact = 1: fp32-input MFMA, bit-exact fp32 fmaf chains (about 1.3x slower at 64 -> 64).
+ * exact = 1: fp32-input MFMA, bit-exact fp32 fmaf chains (about 1.3x slower at 64 -> 64);
+ * exact = 2: bf16x6 split (GWEN_CONTRACT_BF16X6), one more LDS image of the tile.
  * rowptr/col/val here are the GROUPED arrays of gwen_gcn_group8() (rows in whole groups of 8, null
  * group at rowptr[N]; rowptr may be NULL for a uniform layout, see gwen_gcn_group8); x rows must be contiguous (ldx == Fin) and N * Fin * 4 < 2^32.
  * Supported widths: Fin, Fout in {16, 32, 64, 128, 256} (gwen_gcn_layer_supported() says; otherwise
@@ -201,6 +216,9 @@ int gwen_gcn_tiles64(const int32_t *rowptr, const int32_t *col, const float *val
                      int32_t *t_rows, uint16_t *t_lid, float *t_val, int32_t *status,
                      gwen_stream_t stream);
 int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout);
+/* contract: GWEN_CONTRACT_BF16X3 for every supported width pair; GWEN_CONTRACT_BF16X6 for Fin <= 128 (at
+ * Fin = 256 three images of W exceed the registers of the 8 waves that hold them: such layers run on K4). */
+int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract);
 /* 1 when an AUTO layer of these widths over N rows x members is issued as K8 rather than K4 (given a graph
  * that tiles): every supported width pair with Fin >= 128 (measured 1.15x - 1.6x K4), and Fin = 64 once the
  * layer's input no longer sits in the caches (members * N >= 300 000 rows; equal to K4 below that). */
@@ -209,21 +227,21 @@ int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_lid, const 
                             const float *x, const float *W, const float *bias, float *out, int64_t N,
                             int64_t N_src, int64_t Fin, int64_t Fout, int64_t ldo, int64_t members,
                             int64_t mstride_x, int64_t mstride_o, int relu, int64_t union_max,
-                            gwen_stream_t stream);
+                            int contract, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  K4 with the NEXT layer's projection chained on (A~ is linear, so a layer may be gathered at
  * min(Fin, Fout); for a shrinking layer its projection must exist before its gather starts):
  *   pre = 0:  out = act( (A~ x) W1^T + bias ) W2^T     x [.,Fin], W1 [F1,Fin], W2 [F2,F1], F2 < F1
  *   pre = 1:  out = act( A~ h + bias ) W1^T            h [.,Fin] already projected, bias [Fin], F2 = 0
- * rowptr/col/val: GROUPED arrays (rowptr NULL = uniform layout); x, out contiguous rows; widths in {16, 32, 64, 128}; 3xbf16
- * contraction as K4 (exact = 0).  The re-bracketing changes fp32 rounding order only.
+ * rowptr/col/val: GROUPED arrays (rowptr NULL = uniform layout); x, out contiguous rows; widths in {16, 32, 64, 128};
+ * contract: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6, as K4.  The re-bracketing changes fp32 rounding order only.
  * ------------------------------------------------------------------------------------------- */
-int gwen_gcn_chain_supported(int64_t Fin, int64_t F1, int64_t F2, int pre);
+int gwen_gcn_chain_supported(int64_t Fin, int64_t F1, int64_t F2, int pre, int contract);
 int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
                        const float *W1, const float *W2, const float *bias, float *out, int64_t N,
                        int64_t Fin, int64_t F1, int64_t F2, int pre, int relu, int64_t members,
-                       int64_t mstride_x, int64_t mstride_o, gwen_stream_t stream);
+                       int64_t mstride_x, int64_t mstride_o, int contract, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-stack forward == GNNModel.forward (/root/reference/src/gwen/models_gnn.py:292-303 ->
@@ -253,7 +271,7 @@ int gwen_gcn_chain_f32(const int32_t *rowptr, const int32_t *col, const float *v
 #define GWEN_ORDER_AUTO (-1)
 #define GWEN_ORDER_TRANSFORM_FIRST 0
 #define GWEN_ORDER_AGGREGATE_FIRST 1
-#define GWEN_ORDER_FUSED 2         /* K4, 3xbf16 contraction */
+#define GWEN_ORDER_FUSED 2         /* K4, split contraction (gwen_layer_desc.contract) */
 #define GWEN_ORDER_FUSED_EXACT 3   /* K4, fp32 MFMA contraction */
 #define GWEN_KIND_LINEAR 3      /* K3 */
 #define GWEN_KIND_PROPAGATE 2   /* K2 */
@@ -280,6 +298,9 @@ typedef struct gwen_layer_desc {
   const float *bias;
   int32_t fin, fout, relu, order;
   const void *packed;  /* gwen_gcn_small_pack_f32 image of W for K7, or NULL */
+  int32_t contract;    /* AUTO / FUSED layers: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6 (explicit
+                          transform-first / aggregate-first / FUSED_EXACT orders contract in fp32) */
+  int32_t reserved;
 } gwen_layer_desc;
 
 typedef struct gwen_launch_info {
@@ -302,8 +323,10 @@ int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_desc *layers,
  *     square CSR (K1), zero elsewhere; NP = gwen_gcn_small_pad(N) = 128 or 256; dense: fp32 [NP*NP].
  *   gwen_gcn_small_layer_f32: out[m] = act( dense (x[m] W^T) + bias ), x [members, N, Fin] contiguous
  *     rows (member stride mstride_x), W [Fout, Fin], out [members, N, Fout]; Fin % 32 == 0,
- *     Fout % 16 == 0 (gwen_gcn_small_supported).  3xbf16 contractions, fp32 accumulation; the
- *     aggregation is a dense contraction, so only the summation order differs from K2's.
+ *     Fout % 16 == 0 (gwen_gcn_small_supported).  Both contractions on the bf16 split `contract` names
+ *     (GWEN_CONTRACT_BF16X3 or _BF16X6; the packed images serve bf16x3 only: with bf16x6 W is read and split
+ *     in the kernel), fp32 accumulation; the aggregation is a dense contraction, so only the summation order
+ *     differs from K2's.
  *     workspace: gwen_gcn_small_workspace_floats() fp32 elements (0 unless K is cut over blocks).
  *   gwen_gcn_small_pack_f32: W -> its 3xbf16 hi / lo images in MFMA fragment order
  *     (gwen_gcn_small_pack_bytes() bytes, as many as W itself); pass the result as `packed` (W may then
@@ -311,7 +334,7 @@ int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_desc *layers,
  *     when the weights are reused (inference): the C -> 1024 and 1024 -> C layers are bound by reading W.
  * ------------------------------------------------------------------------------------------- */
 int gwen_gcn_small_pad(int64_t N);
-int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout);
+int gwen_gcn_small_supported(int64_t N, int64_t Fin, int64_t Fout, int contract);
 int64_t gwen_gcn_small_workspace_floats(int64_t N, int64_t members, int64_t Fin, int64_t Fout);
 int gwen_gcn_dense_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
                        float *dense, gwen_stream_t stream);
@@ -322,7 +345,7 @@ int gwen_gcn_small_layer_f32(const float *dense, const float *x, const float *W,
                              const float *bias, float *out, int64_t N, int64_t Fin, int64_t Fout,
                              int64_t members,
                              int64_t mstride_x, int64_t mstride_o, int relu, float *workspace,
-                             int64_t workspace_floats, gwen_stream_t stream);
+                             int64_t workspace_floats, int contract, gwen_stream_t stream);
 
 /* hipEvent plumbing for callers without a HIP binding (bench.py times kernels with these, on the
  * stream the kernels are launched on). */
@@ -443,6 +466,27 @@ int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_
                   int64_t R, int64_t F, int act, const int32_t *rowptr, const int32_t *tile_row,
                   int64_t n_tiles, float *agg, int64_t N_agg, int mean, void *workspace,
                   size_t workspace_bytes, gwen_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6^T  pieces of the InteractionNet block's BACKWARD (build-defined like K6; serves the training step of the
+ * reference's loop shape, /root/reference/src/gwen/models_gnn.py:372-373, for the InteractionNet forecaster).
+ * The host (gwen_amd/interaction.py) assembles the backward from K3 (dense products), K2 over CSRs whose columns
+ * are edge positions (sums over the edges of a target / source, in stored order), the weight / bias gradient
+ * reductions below K4's backward, and these three: every launch is atomic-free with a fixed summation order.
+ *   gwen_act_pair_f32:   pre[r] = a[r] + g1[idx1 ? idx1[r] : r] + g2[idx2 ? idx2[r] : r]  (tables optional, row
+ *                        strides ld1 / ld2 >= F);  h[r] = act(pre[r]);  dact[r] = act'(pre[r])  (dact may be NULL;
+ *                        h may alias a).  a, h, dact: [rows, F] contiguous, F % 4 == 0.
+ *   gwen_gather_add_f32: out[r] = (a ? a[r] : 0) + t[idx[r]] * (scale ? scale[idx[r]] : 1)   t: [*, F] contiguous.
+ *   gwen_ew_f32:         out = a * b (GWEN_EW_MUL) or a + b (GWEN_EW_ADD), n % 4 == 0; out may alias a or b.
+ * ------------------------------------------------------------------------------------------- */
+#define GWEN_EW_MUL 0
+#define GWEN_EW_ADD 1
+int gwen_act_pair_f32(const float *a, const float *g1, const int32_t *idx1, int64_t ld1, const float *g2,
+                      const int32_t *idx2, int64_t ld2, float *h, float *dact, int64_t rows, int64_t F, int act,
+                      gwen_stream_t stream);
+int gwen_gather_add_f32(const float *a, const float *t, const int32_t *idx, const float *scale, float *out,
+                        int64_t rows, int64_t F, gwen_stream_t stream);
+int gwen_ew_f32(int op, const float *a, const float *b, float *out, int64_t n, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked L1 loss, value and gradient in one pass -- the reference's training objective

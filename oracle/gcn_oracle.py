@@ -224,6 +224,21 @@ class OracleGNNModel(nn.Module):                  # models_gnn.py:268-303
         return self.conv_layers(x, edge_index)
 
 
+def forward_with_masks(model: "OracleGNNModel", x: Tensor, edge_index: Tensor, masks) -> Tensor:
+    """``OracleGNNModel.forward`` (models_gnn.py:135-157, :189-212) with every ReLU replaced by a GIVEN 0/1
+    activation pattern: ``relu(pre)`` becomes ``pre * mask``.  Autograd through this is the gradient of the
+    network AT that pattern -- the checker for a device backward that ran with the device's own patterns
+    (a pre-activation within rounding of zero may fall on either side of the ReLU; with the pattern fixed, a
+    flipped unit can no longer explain a difference).  ``masks``: five [N, F_l] tensors, one per ReLU."""
+    d, u = model.conv_layers.down_conv_layers, model.conv_layers.up_conv_layers
+    convs = [d.conv1, d.conv2, d.conv3, u.upconv3, u.upconv4]
+    if len(masks) != len(convs):
+        raise ValueError("one mask per ReLU (5)")
+    for conv, m in zip(convs, masks):
+        x = conv(x, edge_index) * m.to(x.dtype)
+    return u.upconv5(x, edge_index)
+
+
 def loss_func(output: Tensor, target: Tensor, target_mask: Tensor) -> Tensor:
     """L1 on masked rows -- the immediate consumer of forward (models_gnn.py:261-265)."""
     return nn.functional.l1_loss(output[target_mask], target[target_mask])

@@ -80,13 +80,20 @@ def test_c3_processor_stack_at_config_size(ga, cref):
     for w, b in params:            # fp64 accumulation of fp32 inputs, layer by layer, then back to fp32 as the device does
         want = cref.conv(want.astype(np.float32), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True)
     g = ga.prepare_graph(ei.to(DEV), n)
-    plan = ga.StackForward([(w.to(DEV), b.to(DEV), True, "auto") for w, b in params], g)
+    # precision "3xbf16": K8, the HBM-leg kernel of bench.py (three images of W exceed its registers at 256 channels)
+    plan = ga.StackForward([(w.to(DEV), b.to(DEV), True, "auto_x3") for w, b in params], g)
     ev = ga.KernelEvents(2 * steps)
     got = plan.run(x.to(DEV), events=ev)
-    assert [k for k, *_ in ev.durations()] == ["wide"] * steps              # K8, the HBM-leg kernel of bench.py
+    assert [k for k, *_ in ev.durations()] == ["wide"] * steps
     assert rel_err(got, want) <= REL_TOL
     assert row_rel_err(got, want) <= 10 * REL_TOL
     assert torch.equal(got, plan.run(x.to(DEV)))
+    # the default precision (bf16x6, fp32-class): K4 at this width, an order of magnitude closer to fp64
+    plan6 = ga.StackForward([(w.to(DEV), b.to(DEV), True, "auto") for w, b in params], g)
+    got6 = plan6.run(x.to(DEV), events=ev)
+    assert [k for k, *_ in ev.durations()] == ["layer"] * steps
+    assert rel_err(got6, want) <= 2e-6 and rel_err(got6, want) < rel_err(got, want)
+    assert torch.equal(got6, plan6.run(x.to(DEV)))
 
 
 def _forecaster_inputs(ga, nu, C, H, steps):

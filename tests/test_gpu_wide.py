@@ -104,6 +104,17 @@ def test_wide_equals_k4_bitwise_and_oracle(ga, cref, fin, fout, nu, reorder):
         ref = cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=relu, f64=True)
         assert rel_err(got, ref) <= 2e-5
     assert torch.equal(ops.wide_layer(g, xd, wd, None), ops.layer_fused(g, xd, wd, None))
+    # bf16x6 on K8: Fin <= 128 on graphs whose unions stay within 128 rows; K4's bf16x6 bit for bit
+    umax = g.tiles()[3]
+    if fin <= 128 and umax <= 128:
+        got6 = ops.wide_layer(g, xd, wd, bd, relu=True, contract="bf16x6")
+        assert torch.equal(got6, ops.layer_fused(g, xd, wd, bd, relu=True, contract="bf16x6")), (fin, fout)
+        ref = cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True)
+        assert rel_err(got6, ref) <= 2e-6
+    else:
+        from gwen_amd._lib import GwenHipError
+        with pytest.raises(GwenHipError):
+            ops.wide_layer(g, xd, wd, bd, relu=True, contract="bf16x6")
 
 
 def test_wide_members_axis_and_few_tiles(ga, cref):

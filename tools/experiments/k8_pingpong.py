@@ -25,7 +25,7 @@ tr, tl, tv, umax = g.tiles()
 L = _lib.lib()
 def layer(src, dst):
     rc = L.gwen_gcn_wide_layer_f32(_ptr(tr), _ptr(tl), _ptr(tv), _ptr(src), _ptr(w), _ptr(b), _ptr(dst), n, n, F, F, F, M,
-                                   n * F, n * F, 1, umax, _stream(torch.device("cuda:0")))
+                                   n * F, n * F, 1, umax, 0, _stream(torch.device("cuda:0")))
     assert rc == 0
 print("same buffers      ", round(timed(lambda i: layer(bufs[0], bufs[1])), 1), "us")
 print("ping-pong 2 bufs  ", round(timed(lambda i: layer(bufs[i & 1], bufs[1 - (i & 1)])), 1), "us")

@@ -32,6 +32,7 @@ def main():
     pts = sys.argv[1:] or ["100:256:1", "100:256:2", "100:256:4", "100:256:8", "100:64:4", "100:64:16",
                            "300:64:1", "300:256:1"]
     which = os.environ.get("KB_WHICH", "k2,k3,k4,k8").split(",")
+    CONTRACT = _lib.CONTRACT_NAMES[os.environ.get("KB_CONTRACT", "3xbf16")]            # K3 / K4 / K8 contraction
     L = _lib.lib()
     dev = torch.device("cuda:0")
     st = _stream(dev)
@@ -62,21 +63,21 @@ def main():
         if "k3" in which:
             nws = int(L.gwen_gcn_linear_workspace_floats(M * N, F, F))
             wsb = torch.empty(max(nws, 1), device=dev)
-            t = timed(lambda: L.gwen_gcn_linear_f32(_ptr(h), _ptr(w), _ptr(b), _ptr(out), M * N, F, F, F, F, 1, 0,
+            t = timed(lambda: L.gwen_gcn_linear_f32(_ptr(h), _ptr(w), _ptr(b), _ptr(out), M * N, F, F, F, F, 1, CONTRACT,
                                                     _ptr(wsb), nws, st))
             c3 = 8 * M * N * F + 4 * F * F
             print(f"   K3 linear    {t:8.1f} us  {c3/t/1e6:5.2f} TB/s compulsory = {c3/t/8e6:.3f}   "
                   f"{2*M*N*F*F/t/1e6:6.1f} TFLOP/s", flush=True)
         if "k4" in which and L.gwen_gcn_layer_supported(F, F):
             t = timed(lambda: L.gwen_gcn_layer_f32(_ptr(gr), _ptr(gc), _ptr(gv), _ptr(h), _ptr(w), _ptr(b), _ptr(out),
-                                                   N, F, F, F, F, M, N * F, N * F, 1, 0, st))
+                                                   N, F, F, F, F, M, N * F, N * F, 1, CONTRACT, st))
             c4 = comp + 4 * F * F
             print(f"   K4 layer     {t:8.1f} us  {c4/t/1e6:5.2f} TB/s compulsory = {c4/t/8e6:.3f} of HBM peak"
                   f"   {M*E/t/1e3:6.2f} Gedge/s", flush=True)
         if "k8" in which and L.gwen_gcn_wide_supported(F, F) and g.tiles() is not None:
             tr, tl, tv, umax = g.tiles()
             t = timed(lambda: L.gwen_gcn_wide_layer_f32(_ptr(tr), _ptr(tl), _ptr(tv), _ptr(h), _ptr(w), _ptr(b), _ptr(out),
-                                                        N, N, F, F, F, M, N * F, N * F, 1 + 2 * int(os.environ.get('KB_DBG', '0')), umax, st))
+                                                        N, N, F, F, F, M, N * F, N * F, 1, umax, CONTRACT, st))
             c4 = comp + 4 * F * F
             print(f"   K8 wide      {t:8.1f} us  {c4/t/1e6:5.2f} TB/s compulsory = {c4/t/8e6:.3f} of HBM peak"
                   f"   {M*E/t/1e3:6.2f} Gedge/s", flush=True)
