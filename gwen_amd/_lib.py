@@ -83,6 +83,7 @@ SIGNATURES = {
                                   _int, _i64, _i64, _i64, _int, _vp]),
     "gwen_gcn_tiles64_count": (_i64, [_i64]),
     "gwen_gcn_tiles64": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gwen_cluster_rows64_host": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gwen_gcn_wide_supported": (_int, [_i64, _i64]),
     "gwen_gcn_wide_preferred": (_int, [_i64, _i64, _i64, _i64]),
     "gwen_gcn_wide_contract_supported": (_int, [_i64, _i64, _int]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgwen_hip.so")
 SOURCES = ["api.hip", "prep.hip", "propagate.hip", "linear.hip", "layer.hip", "chain.hip", "forward.hip", "grad.hip",
-           "interact.hip", "interact_rows.hip", "interact_bwd.hip", "small.hip", "tiles.hip", "wide.hip", "hash.hip", "backward.hip", "loss.hip"]
+           "interact.hip", "interact_rows.hip", "interact_bwd.hip", "small.hip", "tiles.hip", "cluster.hip", "wide.hip", "hash.hip", "backward.hip", "loss.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

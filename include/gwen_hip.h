@@ -215,6 +215,12 @@ int64_t gwen_gcn_tiles64_count(int64_t N);
 int gwen_gcn_tiles64(const int32_t *rowptr, const int32_t *col, const float *val, int64_t N,
                      int32_t *t_rows, uint16_t *t_lid, float *t_val, int32_t *status,
                      gwen_stream_t stream);
+/* HOST arrays in, HOST array out (no device work): a locality order of the rows of a square prepared CSR whose own
+ * numbering has none -- breadth-first balls of GWEN_TILE_ROWS rows grown next to each other over the in-neighbour
+ * lists.  perm [N]: new position -> old row.  Relabel the CSR with it (rows permuted, columns mapped through the
+ * inverse, entry order inside a row kept) and K8 tiles what it could not before; results stay bitwise those of the
+ * unpermuted kernels because every row still sums its entries in stored order. */
+int gwen_cluster_rows64_host(const int32_t *rowptr, const int32_t *col, int64_t N, int64_t N_src, int32_t *perm);
 int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout);
 /* contract: GWEN_CONTRACT_BF16X3 for every supported width pair; GWEN_CONTRACT_BF16X6 for Fin <= 128 (at
  * Fin = 256 three images of W exceed the registers of the 8 waves that hold them: such layers run on K4). */

@@ -157,3 +157,59 @@ def test_c5_forecaster_step_256ch_at_config_size_closed_forms(ga):
         vg = x0.double() @ model.grid_embed.weight.double().cpu().t() + model.grid_embed.bias.double().cpu()
         want = x0.double() + vg @ w_keep.double().cpu().t() + b_keep.double().cpu()
     assert rel_err(got, want) <= REL_TOL
+
+
+def test_c5_rollout_four_members_four_steps(ga):
+    """BASELINE configs[4] per GPU: 4 members x 4 autoregressive steps through ``ensemble_forecast`` (all members in
+    one launch set per step, the step captured once and replayed) on the nu = 100 graphs.  64 channels: one member's
+    whole trajectory against the fp64 oracle stepped four times; 256 channels (the config's width; an fp64 oracle
+    rollout there is many minutes of CPU): bitwise determinism, batched == member by member, and the closed form of
+    a zero read-out (every step is the identity on the grid state)."""
+    from gwen_amd import g2m
+    from gwen_amd.forecaster import InteractionForecaster, edge_features, ensemble_forecast
+    from oracle import interaction_oracle as IO
+    members, n_steps, blocks = 4, 4, 4
+    # ---- 64 channels vs the oracle -------------------------------------------------------------------------------
+    C, H = 8, 64
+    m, model, _ = _forecaster_inputs(ga, 100, C, H, blocks)
+    n_grid = m.faces.shape[0]
+    xs = torch.stack([torch.randn(n_grid, C, generator=torch.Generator().manual_seed(SEED + k)) * 0.5
+                      for k in range(members)])
+    a, b = g2m.grid_mesh_edges(m)
+    cell = m.pos[m.faces].mean(axis=1)
+    cell /= np.linalg.norm(cell, axis=1, keepdims=True)
+    f = [torch.from_numpy(v).double() for v in (edge_features(cell, m.pos, a), edge_features(m.pos, m.pos, m.edge_index),
+                                                 edge_features(m.pos, cell, b))]
+    sd = {k: v.double() for k, v in model.state_dict().items()}
+    pos64 = torch.from_numpy(m.pos.astype(np.float32)).double()
+    pick = 2
+    want = xs[pick].double()
+    for _ in range(n_steps):
+        want = IO.forecaster_step(sd, want, pos64, torch.from_numpy(a), torch.from_numpy(m.edge_index),
+                                  torch.from_numpy(b), *f, blocks)
+    graphs = InteractionForecaster.prepare(m, DEV)
+    model = model.to(DEV).eval()
+    cache = {}
+    got = ensemble_forecast(model, graphs, xs.to(DEV), n_steps, members, graphed=True, batched=True, step_cache=cache)
+    assert got.shape == (members, n_grid, C) and torch.isfinite(got).all()
+    assert rel_err(got[pick], want) <= REL_TOL
+    assert torch.equal(got, ensemble_forecast(model, graphs, xs.to(DEV), n_steps, members, graphed=True, batched=True,
+                                              step_cache=cache))
+    del graphs, model, cache
+    torch.cuda.empty_cache()
+    # ---- 256 channels: the config's width -----------------------------------------------------------------------------
+    H = 256
+    m, model, _ = _forecaster_inputs(ga, 100, C, H, blocks)
+    graphs = InteractionForecaster.prepare(m, DEV)
+    model = model.to(DEV).eval()
+    xd = xs.to(DEV)
+    cache = {}
+    got = ensemble_forecast(model, graphs, xd, n_steps, members, graphed=True, batched=True, step_cache=cache)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ensemble_forecast(model, graphs, xd, n_steps, members, graphed=True, batched=True,
+                                              step_cache=cache))                        # replayed: same bits
+    one_by_one = ensemble_forecast(model, graphs, xd, n_steps, members, graphed=False, batched=False)
+    assert torch.equal(got, one_by_one)                                                 # block-diagonal batch == loop
+    with torch.no_grad():
+        model.readout.weight.zero_(); model.readout.bias.zero_()
+    assert torch.equal(ensemble_forecast(model, graphs, xd, n_steps, members, graphed=False, batched=True), xd)
