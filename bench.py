@@ -216,9 +216,19 @@ def pmc_traffic(tag_prefixes):
     except (OSError, KeyError, ValueError):
         return None
     for k_, v in tf.items():
-        if any(k_.startswith(t) for t in tag_prefixes):
-            return v["hbm_bytes_per_launch"]
+        for t in tag_prefixes:
+            pre, suf = t if isinstance(t, tuple) else (t, "")
+            if k_.startswith(pre) and k_.endswith(suf):
+                return v["hbm_bytes_per_launch"]
     return None
+
+
+def kernel_tags(kind, fin, fout, ns):
+    """Name patterns (prefix, suffix) of the kernel a launcher `kind` ran, as rocprofv3 prints it; ns = bf16 images
+    per operand (2: bf16x3, 3: bf16x6, 0: fp32 MFMA) -- a template argument of every contracting kernel."""
+    return {"wide": [(f"k_wide<{fin}, {fout},", f", {ns}>")], "layer": [(f"k_layer<{fin}, {fout}, {ns},", "")],
+            "propagate": ["k_propagate<"], "linear": ["k_linear"],
+            "chain": [(f"k_chain<{fin},", f", {ns}>"), "k_gather<"]}[kind]
 
 
 class Sampler:
@@ -319,8 +329,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
     avg = tot / cnt
     comp = compulsory_bytes(kind, n, e, fin, fout, m)
     ws_mib = 2 * 4 * m * n * f / 2 ** 20
-    tags = {"wide": [f"k_wide<{fin}, {fout},"], "layer": [f"k_layer<{fin}, {fout},"],
-            "propagate": ["k_propagate<"], "linear": ["k_linear<"], "chain": [f"k_chain<{fin},"]}[kind]
+    tags = kernel_tags(kind, fin, fout, 3 if order == "auto" else 2)
     # one member against the CPU oracle's first layer would take minutes at this width; parity at this size
     # is tests/test_gpu_wide.py::test_c3_layer_at_config_size_four_members
     return {
@@ -671,8 +680,7 @@ def main():
     b_comp = compulsory_bytes(kind, n, e, fin, fout, m_local)
     avg_s = total_s / launches
     achieved = b_l2 / avg_s / 1e9
-    tag = {"layer": [f"k_layer<{fin}, {fout},"], "chain": [f"k_chain<{fin},"], "linear": ["k_linear<"],
-           "propagate": ["k_propagate<"], "wide": [f"k_wide<{fin}, {fout},"]}[kind]
+    tag = kernel_tags(kind, fin, fout, {"auto": 3, "unfused": 3, "bf16x3": 2, "fused_exact": 0}[args.order])
     default_c2 = (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1)
     per_layer_us = {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())}
     roofline = {

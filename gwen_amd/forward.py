@@ -147,6 +147,8 @@ class StackForward:
         # whose fused kernels walk a row serially
         self._long = (not self._small) and graph.long_row_levels() is not None
         self._layers = list(layers)
+        self._packed_in = packed
+        self._inner: dict = {}               # members -> (perm, inv_perm, StackForward on the clustered graph) or None
         self._scratch: Optional[Tensor] = None
         self._scratch_key = None
         self._gd = None
@@ -189,6 +191,23 @@ class StackForward:
             self._gd, self._gd_key = gd, key
         return self._gd
 
+    def _clustered_plan(self, members: int):
+        """A caller's arbitrary node order does not tile, so its wide AUTO layers would fall back from K8 to K4
+        (0.28 of the HBM peak beyond the caches against 0.4-0.5): when some layer wants K8 and the graph tiles only
+        in an order this library grows itself (``GraphCSR.clustered``), the whole stack runs in that order --
+        input rows permuted once, output rows permuted back -- with bitwise the same results."""
+        if members not in self._inner:
+            g, hit = self.graph, None
+            wants = (not self._small) and (not self._long) and g.num_src < 0 and any(
+                d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_wide_preferred(g.num_nodes, members, d.fin, d.fout)
+                and _lib.lib().gwen_gcn_wide_contract_supported(d.fin, d.fout, d.contract) for d in self.desc)
+            if wants and g.tiles() is None:
+                cl = g.clustered()
+                if cl is not None:
+                    hit = (cl[0], cl[1], StackForward(self._layers, cl[2], self._packed_in))
+            self._inner[members] = hit
+        return self._inner[members]
+
     def run(self, x: Tensor, out: Optional[Tensor] = None,
             events: Optional[KernelEvents] = None, acts: Optional[List[Tensor]] = None) -> Tensor:
         """``acts``: list of n_layers output tensors ([..., N, fout_l]) -- the TRAINING forward: every
@@ -207,6 +226,15 @@ class StackForward:
         n = self.graph.num_nodes
         if x.size(-2) != n or x.size(-1) != self.fin:
             raise ValueError(f"x is {tuple(x.shape)}, expected [..., {n}, {self.fin}]")
+        if acts is None:
+            inner = self._clustered_plan(members)
+            if inner is not None:
+                perm, inv, plan = inner
+                y = plan.run(x.index_select(-2, perm), events=events)
+                if out is None:
+                    return y.index_select(-2, inv)
+                torch.index_select(y, -2, inv, out=out)
+                return out
         if self._long:
             from . import ops
             cur = x

@@ -53,6 +53,7 @@ class GraphCSR:
     _tiles: Optional[tuple] = field(default=None, repr=False)
     _tgraph: Optional["GraphCSR"] = field(default=None, repr=False)
     _levels: Optional[tuple] = field(default=None, repr=False)
+    _clustered: Optional[tuple] = field(default=None, repr=False)
 
     @property
     def device(self) -> torch.device:
@@ -96,6 +97,56 @@ class GraphCSR:
                 flag, umax = (int(v) for v in st.tolist())
                 self._tiles = ((t_rows, t_lid, t_val, umax),) if flag == 0 else (None,)
         return self._tiles[0]
+
+    def clustered(self) -> Optional[Tuple[Tensor, Tensor, "GraphCSR"]]:
+        """For a square bounded-degree graph whose OWN node numbering does not tile (``tiles()`` is None because
+        64 consecutive rows name more than 192 distinct sources -- an arbitrary ``edge_index`` order): the graph
+        relabelled by a locality order this library grows itself (``gwen_cluster_rows64_host``: breadth-first
+        balls of 64 rows) -- ``(perm, inv_perm, graph_p)`` with ``perm[new] = old`` (int64 device tensors) and
+        ``graph_p`` the same CSR in the new numbering (rows permuted, columns mapped, entry order inside a row
+        kept: every row sums the same terms in the same order, so K8 on ``graph_p`` is bitwise K4 on this graph).
+        None when the relabelled graph does not tile either (rows beyond 8 entries, hubs).  Built on first use:
+        one host round trip of the CSR (two int32 arrays), once per graph."""
+        if self._clustered is None:
+            self._clustered = (self._cluster_impl(),)
+        return self._clustered[0]
+
+    def _cluster_impl(self):
+        n, dev = self.num_nodes, self.device
+        if self.num_src >= 0 or n < 2 * 64:
+            return None
+        lens = self.rowptr[1:] - self.rowptr[:-1]
+        if int(lens.max().item()) > 8:
+            return None
+        import numpy as np
+        rp = self.rowptr.cpu().numpy()
+        nnz = int(rp[-1])
+        cl = self.col[:nnz].cpu().numpy()
+        perm_h = np.empty(n, dtype=np.int32)
+        rc = _lib.lib().gwen_cluster_rows64_host(rp.ctypes.data, cl.ctypes.data, n, n, perm_h.ctypes.data)
+        _lib.check(rc, "gwen_cluster_rows64_host")
+        perm = torch.from_numpy(perm_h).to(dev).long()
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n, device=dev)
+        new_len = lens.long().index_select(0, perm)
+        new_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        new_rowptr[1:] = torch.cumsum(new_len, 0)
+        start_old = self.rowptr[:-1].long().index_select(0, perm)
+        within = torch.arange(nnz, device=dev) - new_rowptr[:-1].repeat_interleave(new_len)
+        src_pos = start_old.repeat_interleave(new_len) + within           # old entry position of every new entry
+        pad = self.col.numel() - nnz                                       # keep the arrays' slack (vector reads)
+        col_p = torch.zeros_like(self.col)
+        val_p = torch.zeros_like(self.val)
+        eid_p = torch.full_like(self.eid, -1)
+        col_p[:nnz] = inv.index_select(0, self.col[:nnz].long().index_select(0, src_pos)).to(torch.int32)
+        val_p[:nnz] = self.val[:nnz].index_select(0, src_pos)
+        eid_p[:nnz] = self.eid[:nnz].index_select(0, src_pos)
+        del pad
+        gp = GraphCSR(n, self.num_edges, new_rowptr.to(torch.int32), col_p, val_p, eid_p,
+                      self.dis.index_select(0, perm) if self.dis.numel() == n else self.dis, self.status)
+        if gp.tiles() is None:
+            return None
+        return perm, inv, gp
 
     def transposed_grouped(self) -> Tuple[Optional[Tensor], Tensor, Tensor]:
         """Grouped layout (gwen_gcn_group8) of the TRANSPOSED CSR: what K4's kernel walks in the backward

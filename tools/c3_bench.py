@@ -2,11 +2,18 @@
 (default 4 "processor steps"), M members (default 1; 4 = config c5's per-GPU load).  One JSON line: us per
 sequence and per pass, edges/s per pass, the roofline of one pass (compulsory bytes / time / 8 TB/s, and
 SURVEY 8(d)'s L2-path bytes beside it), and the relative error of one member against the plain-C oracle
-(oracle/gcn_ref.c, fp64) chained on the host.     python tools/c3_bench.py [F] [S] [M]"""
+(oracle/gcn_ref.c, fp64) chained on the host.     python tools/c3_bench.py [F] [S] [M] [--precision bf16x6|3xbf16]
+(default: the library default bf16x6 -- K4 at 256 channels; 3xbf16 -- K8, the tile-staged kernel)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch, gwen_amd
+PREC = "bf16x6"
+if "--precision" in sys.argv:
+    i = sys.argv.index("--precision")
+    PREC = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+ORDER = {"bf16x6": "auto", "3xbf16": "auto_x3"}[PREC]
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -19,7 +26,7 @@ for _ in range(S):
     conv = gwen_amd.GCNConv(F, F).to(dev)
     with torch.no_grad():
         conv.bias.normal_(0, 0.1)
-    layers.append((conv.lin.weight.detach(), conv.bias.detach(), True, "auto"))
+    layers.append((conv.lin.weight.detach(), conv.bias.detach(), True, ORDER))
 g = gwen_amd.prepare_graph(torch.from_numpy(mesh.edge_index).to(dev), n)
 plan = gwen_amd.StackForward(layers, g)
 x = torch.randn(M, n, F, device=dev) if M > 1 else torch.randn(n, F, device=dev)
@@ -40,7 +47,7 @@ dt = (time.perf_counter() - t0) / K
 per_pass = dt / S
 comp = 8 * M * n * F + 8 * (e + n) + 4 * n + 4 * F * F
 b_l2 = M * (4 * F * (e + 2 * n) + 8 * e + 8 * n)
-rec = {"workload": f"c3: nu=100 N={n} E={e}, {S} chained GCN layers {F}->{F} + ReLU, {M} member(s)",
+rec = {"workload": f"c3: nu=100 N={n} E={e}, {S} chained GCN layers {F}->{F} + ReLU, {M} member(s)", "precision": PREC,
        "kernels": kinds, "us_per_sequence": round(dt * 1e6, 1), "us_per_pass": round(per_pass * 1e6, 1),
        "edges_per_s_per_pass": round(M * e / per_pass),
        "roofline": {"bound": "hbm" if 8 * M * n * F > 256 * 2 ** 20 else "l2/infinity-cache (in+out fit 256 MiB)",

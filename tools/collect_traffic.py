@@ -21,7 +21,7 @@ def per_kernel(pattern, counter):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(k_(?:layer|chain|gather|propagate|linear|wide|mlp2r|mlp2)<[^>]*>)", r["Kernel_Name"])
+            m = re.search(r"(k_(?:layer|chain|gather|propagate|linear_split|linear|wide|mlp2r|mlp2)<[^>]*>)", r["Kernel_Name"])
             if m:
                 agg[m.group(1)].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
