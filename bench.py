@@ -75,6 +75,10 @@ def parse():
     p.add_argument("--launch-dry-run", action="store_true",
                    help="with --gpus N > 1 and no WORLD_SIZE in the environment: print the N child command lines "
                         "and their rank environments as one JSON object and exit without starting them")
+    p.add_argument("--rehearse-gloo", action="store_true",
+                   help="REHEARSAL of the N > 1 code path on a box with fewer GPUs than ranks: every rank uses GPU 0 and "
+                        "the process group is gloo (RCCL refuses two ranks on one device), the gather goes through the "
+                        "host.  The line says so (allgather.backend = gloo, config.rehearsal); not a measurement")
     p.add_argument("--rollout-steps", type=int, default=4, help="c5: autoregressive steps per rollout")
     p.add_argument("--c5-channels", type=int, default=256, help="c5: grid channels = hidden width")
     p.add_argument("--c5-blocks", type=int, default=4, help="c5: mesh->mesh processor blocks")
@@ -371,11 +375,16 @@ def init_ranks(args):
         raise SystemExit(0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     return world, rank, dev
 
 
@@ -495,7 +504,7 @@ def run_c5(args, world, rank, dev):
                    "grid_nodes": n_grid, "mesh_nodes": n_mesh, "edge_updates_per_model_step": edges,
                    "channels": ch, "processor_blocks": nb, "rollout_steps": r_steps, "members": members,
                    "node_order": args.reorder, "contraction": "3xbf16-split (fp32 storage and accumulation)",
-                   "hip_graph": True,
+                   "hip_graph": True, "rehearsal": "gloo, all ranks on GPU 0" if args.rehearse_gloo else None,
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} members; one all-gather at end"},
         "edge_updates_per_s": members * r_steps * edges * args.steps / elapsed,
     }
@@ -720,7 +729,7 @@ def main():
                                    "bf16x3": "bf16x3 split: two bf16 images per operand, three MFMA terms",
                                    "fused_exact": "fp32-input MFMA (exact fp32 products)",
                                    "unfused": "bf16x6 split in K3"}[args.order],
-                   "hip_graph": bool(args.graph),
+                   "hip_graph": bool(args.graph), "rehearsal": "gloo, all ranks on GPU 0" if args.rehearse_gloo else None,
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
         "members_per_s": members * args.steps / elapsed,
         "edges_per_s_64ch_pass": pass64,

@@ -51,6 +51,10 @@ def gather_members(local: Tensor, num_members: int, group: Optional[dist.Process
     if local.size(0) != counts[rank]:
         raise ValueError(f"rank {rank} holds {local.size(0)} members, expected {counts[rank]}")
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the N > 1 path without RCCL (bench.py --rehearse-gloo: several ranks on one GPU): gloo
+        # gathers host tensors, so the shards go through the host -- never the measured configuration
+        return gather_members(local.cpu(), num_members, group).to(local.device)
     tail = tuple(local.shape[1:])
     if len(set(counts)) == 1:
         out = torch.empty((num_members,) + tail, dtype=local.dtype, device=local.device)

@@ -119,3 +119,27 @@ def test_c5_bench_line_on_a_small_run(hip_lib):
     assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
     assert d["cpu_baseline"]["gpu_vs_oracle_rel_err_one_step"] <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_two_ranks_self_launched_rehearsal(hip_lib, workload):
+    """`python bench.py --gpus 2` with NO launcher: the parent starts both ranks itself and the N > 1 path runs end to
+    end -- member sharding, MAX-reduced timing, the one gather inside the timed region, the `allgather` object.  A
+    one-GPU box cannot give RCCL two devices, so this is the rehearsal mode (both ranks on GPU 0, gloo, the gather
+    through the host): it proves the code path the driver's 2/4/8-GPU runs take, not a number."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--steps", "3", "--warmup", "1",
+           "--prewarm-ms", "10"]
+    if workload == "c5":
+        cmd += ["--workload", "c5", "--c5-channels", "64", "--c5-members-per-gpu", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rehearsal"]
+    ag = d["allgather"]
+    assert ag["ranks_seen"] == 2 and ag["world_size"] == 2 and ag["backend"] == "gloo" and ag["bytes_per_rank"] > 0
+    assert d["config"]["members"] == (2 if workload == "c2" else 4)
+    assert d["value"] > 0 and "cpu_baseline" not in d and "hbm_leg" not in d
