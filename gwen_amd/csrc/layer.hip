@@ -269,7 +269,11 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
     return GWEN_ROWS(64, false, nullptr);
   } else {
     // rows per block: enough that W (read once per block) stays a small fraction of the gathered bytes
-    constexpr int BRMIN = FIN == 128 ? 128 : 64;     // 256: 64 rows keep two blocks per CU in LDS
+#ifndef K4_BR256X6
+#define K4_BR256X6 64
+#endif
+    // 256: 64 rows keep two blocks per CU in LDS (bf16x3); K4_BR256X6: rows per block at 256 channels on bf16x6
+    constexpr int BRMIN = FIN == 128 ? 128 : (FIN == 256 && NS == 3 ? K4_BR256X6 : 64);
     return GWEN_ROWS(BRMIN, false, nullptr);
   }
 #undef GWEN_ROWS

@@ -728,7 +728,10 @@ extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
 extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract) {
   if (!gwen_gcn_wide_supported(Fin, Fout)) return 0;
   if (contract == GWEN_CONTRACT_BF16X3) return 1;
-  return contract == GWEN_CONTRACT_BF16X6 && Fin <= 128 ? 1 : 0;   // three images of W: 192 registers at Fin = 256
+  // bf16x6 at 256 -> 256: three images of W are 192 of the 256 registers a wave has there -- hipcc spills 85-91 of
+  // them and the kernel runs 141-157 us per pass on one member against K4's 127 (measured): refused, the planner
+  // takes K4.  256 -> 64 / 128 hold half / a quarter of the columns per wave and fit.
+  return contract == GWEN_CONTRACT_BF16X6 && (Fin <= 128 || Fout <= 128) ? 1 : 0;
 }
 
 extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
@@ -768,7 +771,7 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
 #define GWEN_W(FI, FO)                                                                                \
   if (Fin == FI && Fout == FO) {                                                                      \
     constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
-    if constexpr (FI <= 128) {                                                                        \
+    if constexpr (FI <= 128 || FO <= 128) {                                                           \
       if (x6) return launch<FI, FO, NWV, 1, 128, true, false, 3>(GWEN_ARGS);                          \
     }                                                                                                 \
     return small_union ? launch<FI, FO, NWV, 1, 128, true>(GWEN_ARGS)                                 \
