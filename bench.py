@@ -410,7 +410,7 @@ def cpu_model_name():
         return "unknown CPU"
 
 
-def cpu_thread_sweep(fn, budget_s, counts=None):
+def cpu_thread_sweep(fn, budget_s, counts=None, warm=True):
     """Median time of fn() at each thread count (1, 8, 16, 32, 64, all -- those the host has); returns
     (best_threads, best_median, {threads: (median, reps)}, last result).  The stated baseline is the BEST
     configuration found, not the widest one (torch's index_add_ does not scale with threads)."""
@@ -421,10 +421,10 @@ def cpu_thread_sweep(fn, budget_s, counts=None):
     for th in counts:
         torch.set_num_threads(th)
         with torch.no_grad():
-            tw = time.perf_counter(); last = fn(); one = time.perf_counter() - tw       # warm-up
+            tw = time.perf_counter(); last = fn(); one = time.perf_counter() - tw       # warm-up (or the only pass)
             reps = max(1, min(20, int(per_leg / max(one, 1e-3))))
-            ts = []
-            for _ in range(reps):
+            ts = [] if warm else [one]
+            for _ in range(reps if warm else 0):
                 tw = time.perf_counter(); last = fn(); ts.append(time.perf_counter() - tw)
         res[th] = (sorted(ts)[len(ts) // 2], reps)
     torch.set_num_threads(all_cores)
@@ -559,7 +559,7 @@ def c5_cpu_baseline(IO, model, mesh, graphs, x, out, args, members, elapsed):
     with torch.no_grad():
         best_t, med, sweep, y1 = cpu_thread_sweep(
             lambda: IO.forecaster_step(sd, xc, pos, *eis, *feats, args.c5_blocks), args.cpu_seconds,
-            counts=sorted({c_ for c_ in (1, 8, 32, all_c) if c_ <= all_c}))
+            counts=sorted({min(8, all_c), min(32, all_c)}), warm=False)   # one pass each: a step is ~10 s of CPU
     # one device step of the same member against it
     with torch.no_grad():
         got = model(x[0], graphs).cpu()

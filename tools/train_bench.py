@@ -1,5 +1,8 @@
 """Training step (forward + L1 loss on masked rows + backward + Adam) of GNNModel on the c2 mesh and on the
-reference's own shape: ms per step.   python tools/train_bench.py [mesh|ref]"""
+reference's own shape: ms per step.   python tools/train_bench.py [mesh|ref] [fused] [graph]
+fused: torch.optim.Adam(fused=True);  graph: the WHOLE step (forward, loss, backward, Adam) captured once into a
+hipGraph (torch.cuda.CUDAGraph) and replayed -- every launcher of libgwen_hip.so is capturable (no allocation, no
+synchronisation inside), so the step leaves the host's per-launch cost behind."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gwen_amd
@@ -14,7 +17,9 @@ else:
     n, c, h = 125, 16384, 1024
     ei = torch.from_numpy(gwen_amd.complete_graph(n)).to(dev)
 model = gwen_amd.GNNModel(gwen_amd.GNNConfig(n, n, c, c, h)).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused="fused" in sys.argv)   # the reference: the default (foreach)
+GRAPH = "graph" in sys.argv
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=("fused" in sys.argv) or GRAPH,
+                       capturable=GRAPH)   # the reference: the default (foreach)
 x = torch.randn(n, c, device=dev)
 mask = torch.rand(n, device=dev) < 0.5
 def step():
@@ -24,15 +29,41 @@ def step():
     loss.backward()
     opt.step()
     return loss
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
 K = 30
-for _ in range(K):
-    step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / K
+if GRAPH:
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up off the default stream, as capture requires
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        out = model(x, ei)
+        loss = gwen_amd.loss_func(out, x, mask)
+        loss.backward()
+        opt.step()
+    first = float(loss)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    assert float(loss) < first or abs(float(loss) - first) < 1e-3 * abs(first), (first, float(loss))   # it trains
+    t0 = time.perf_counter()
+    for _ in range(K):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+else:
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
 with torch.no_grad():
     model.eval()
     for _ in range(3):
@@ -43,4 +74,4 @@ with torch.no_grad():
         model(x, ei)
     torch.cuda.synchronize()
     df = (time.perf_counter() - t0) / K
-print(("fused Adam, " if "fused" in sys.argv else "") + f"{which}: N={n} C={c} H={h}: training step {dt*1e3:.3f} ms, inference forward {df*1e3:.3f} ms")
+print(("whole step replayed from a hipGraph, " if GRAPH else "") + ("fused Adam, " if "fused" in sys.argv else "") + f"{which}: N={n} C={c} H={h}: training step {dt*1e3:.3f} ms, inference forward {df*1e3:.3f} ms")
