@@ -46,6 +46,12 @@
 #ifndef K8_PRIO       // experiment: s_setprio around the MFMA half
 #define K8_PRIO 0
 #endif
+#ifndef K8_NT_LD      // 1: non-temporal staging loads too (variant builds; measured: see glds16_p)
+#define K8_NT_LD 0
+#endif
+#ifndef K8_LD_POLICY  // experiment: cache policy of the staging DMAs (" nt", " sc1", ...)
+#define K8_LD_POLICY ""
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -91,12 +97,22 @@ __device__ inline const char *uniform_ptr(const void *p) {
   return reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
 }
 
-// one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) to LDS byte address dst + 16 l
-__device__ inline void glds16(const void *base, uint32_t voff, uint32_t dst) {
+// one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) to LDS byte address dst + 16 l.
+// nt: non-temporal cache policy for the staging loads (-DK8_NT_LD=1; off in the product).  Measured in the 4-layer
+// stacks, two A/B repeats on one box: 64 -> 64 x 16 members bf16x6 214.4 -> 209.1 us, but bf16x3 198.0 -> 203.0 and
+// 256 -> 256 x 4 members 242.0 -> 249.2: the halo rows neighbouring tiles share are re-read from L2 shortly after,
+// and nt lines leave it first.
+template <bool NT>
+__device__ inline void glds16_p(const void *base, uint32_t voff, uint32_t dst) {
   uint32_t keep;       // M0 is compiler-reserved: save and restore it inside the statement
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  if constexpr (NT)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  else
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2" K8_LD_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
@@ -142,6 +158,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   static_assert(kLds <= 160 * 1024, "the block's LDS exceeds a CU's");
   static_assert(!DENSE || KU == kRows, "a dense tile stages its own rows");
   const uint32_t row_pitch = DENSE ? (uint32_t)ldx * 4u : (uint32_t)(FIN * 4);
+  auto glds16 = [&](const void *base, uint32_t voff, uint32_t dst) {     // nt is wave-uniform (a kernel argument)
+    if (nt && K8_NT_LD) glds16_p<true>(base, voff, dst);
+    else glds16_p<false>(base, voff, dst);
+  };
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

@@ -86,7 +86,8 @@ class GCNConv(nn.Module):
         "fp32": the fp32-input MFMA (exact fp32 products, bit-identical to a k-ordered fmaf chain).  The same
         rule holds in training (forward; the backward contracts with "3xbf16") and inference, in the per-layer
         path and in the stack launcher."""
-        return {"auto": "bf16x6", "auto_x3": "3xbf16"}.get(self.order, "fp32")
+        from .ops import contract_of_order
+        return contract_of_order(self.order)
 
     @precision.setter
     def precision(self, value: str) -> None:
