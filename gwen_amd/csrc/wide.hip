@@ -46,6 +46,9 @@
 #ifndef K8_PRIO       // experiment: s_setprio around the MFMA half
 #define K8_PRIO 0
 #endif
+#ifndef K8_ABL_NOWLO  // TIMING ABLATION (results wrong by construction): W's second image is not kept -- what would
+#define K8_ABL_NOWLO 0 // 16 waves at Fin = 256 buy if W's low image did not occupy registers?  (-DK8_ABL_NOWLO=1)
+#endif
 #ifndef K8_NT_LD      // 1: non-temporal staging loads too (variant builds; measured: see glds16_p)
 #define K8_NT_LD 0
 #endif
@@ -78,6 +81,49 @@ template <int NS>
 __device__ inline void split4n(const float4_t &a, bf16x4 (&im)[NS]) {
   const float f4[4] = {a[0], a[1], a[2], a[3]};
   gwen::split_images<4, NS>(f4, im);
+}
+
+#ifndef K8_RELU_IMAX  // 1: ReLU as a signed-integer max on the float's bits (one instruction per element)
+#define K8_RELU_IMAX 1
+#endif
+// ReLU of four values.  `x < 0 ? 0 : x` keeps NaN (as torch.relu does) but is a compare + select per element;
+// max(bits(x), 0) on the bits as SIGNED integers is one v_max_i32: a float with the sign bit clear is a
+// non-negative integer and stays, one with the sign bit set is a negative integer and becomes +0 -- identical for
+// every finite value, -0 and +-Inf, and a NaN with a clear sign bit (the one arithmetic produces here: Inf - Inf,
+// 0 * Inf give 0x7fc00000 on gfx950) stays a NaN; only a NaN carrying a SET sign bit would read as 0.
+// `floor_bits` = 0 with the ReLU, INT_MIN without (max with INT_MIN changes nothing): no branch, no select.
+__device__ inline float4_t relu4(float4_t v, int relu, int floor_bits) {
+#if K8_RELU_IMAX
+  typedef int int4_t __attribute__((ext_vector_type(4)));
+  int4_t b = __builtin_bit_cast(int4_t, v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = b[e] > floor_bits ? b[e] : floor_bits;
+  return __builtin_bit_cast(float4_t, b);
+#else
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+  }
+  return v;
+#endif
+}
+
+#ifndef K8_FMA        // 0: vector fma (hipcc emits v_pk_fma_f32 + a move per weight); 1: four v_fma_f32, weight as an
+#define K8_FMA 1      // operand -- 1.3-1.7 % faster at 256 channels (245.0 / 242.6 vs 248.2 / 246.8 us, A/B on one box), equal at 64
+#endif
+// acc + w * v on four lanes of a row (fused: one rounding per element either way, the same bits)
+__device__ inline float4_t fma4(float w, const float4_t &v, float4_t acc) {
+#if K8_FMA == 1
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float r = acc[e];
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(r) : "v"(w), "v"(v[e]));      // opaque to the vectoriser
+    acc[e] = r;
+  }
+  return acc;
+#else
+  return __builtin_elementwise_fma(float4_t{w, w, w, w}, v, acc);
+#endif
 }
 
 template <int N, typename F, int I = 0>
@@ -158,6 +204,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   static_assert(kLds <= 160 * 1024, "the block's LDS exceeds a CU's");
   static_assert(!DENSE || KU == kRows, "a dense tile stages its own rows");
   const uint32_t row_pitch = DENSE ? (uint32_t)ldx * 4u : (uint32_t)(FIN * 4);
+  const int floor_bits = relu ? 0 : (int)0x80000000;     // relu4
   auto glds16 = [&](const void *base, uint32_t voff, uint32_t dst) {     // nt is wave-uniform (a kernel argument)
     if (nt && K8_NT_LD) glds16_p<true>(base, voff, dst);
     else glds16_p<false>(base, voff, dst);
@@ -191,7 +238,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   // ---- W fragments (this wave's CT x 16 output columns, all of Fin) -- as K4; bias -> LDS ---------------
   const int jw = NJ >= NW ? wave : wave % NJ;                  // this wave's column tiles: CT jw .. + CT - 1
   const int tt0 = NJ >= NW ? 0 : wave / NJ;                    // its first row tile
-  bf16x8 bw[CT][KS][NS];
+  constexpr int NSW = K8_ABL_NOWLO ? 1 : NS;            // W images kept in registers
+  bf16x8 bw[CT][KS][NSW];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int j = CT * jw + ct;                                // adjacent tiles: full 128-B lines per row
@@ -202,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       const float4_t w0 = *reinterpret_cast<const float4_t *>(wp);
       const float4_t w1 = *reinterpret_cast<const float4_t *>(wp + 4);
       const float w8[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-      gwen::split_images<8, NS>(w8, bw[ct][ks]);
+      gwen::split_images<8, NSW>(w8, bw[ct][ks]);
     }
   }
   {
@@ -214,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)       // every global load above is waited for here, not inside the pipeline
 #pragma unroll
-      for (int s_ = 0; s_ < NS; ++s_) asm volatile("" : "+v"(bw[ct][ks][s_]));
+      for (int s_ = 0; s_ < NSW; ++s_) asm volatile("" : "+v"(bw[ct][ks][s_]));
 
   // ---- pipeline pieces ------------------------------------------------------------------------------------
   // DMA of (tile g, chunk c) into stage[sb]; with c == 0 also the tile's entry weights / local ids into
@@ -312,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float w = wgt[p][hf][u];
-          acc[p] = __builtin_elementwise_fma(float4_t{w, w, w, w}, v[p][u], acc[p]);
+          acc[p] = fma4(w, v[p][u], acc[p]);
         }
     }
 #pragma unroll
@@ -348,7 +396,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          a4 = __builtin_elementwise_fma(float4_t{w4[u], w4[u], w4[u], w4[u]}, vv[u], a4);
+          a4 = fma4(w4[u], vv[u], a4);
       }
       bf16x4 im[NS];
       split4n<NS>(a4, im);
@@ -382,10 +430,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         const int j = CT * jw + ct;
         float4_t o = float4_t{d[ct][i][0], d[ct][i][1], d[ct][i][2], d[ct][i][3]} +
                      *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
-        if (relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
-        }
+        o = relu4(o, relu, floor_bits);
         float *dst = om + (int64_t)r * ldo + j * 16 + 4 * mh;
         if (whole || r < N) *reinterpret_cast<float4_t *>(dst) = o;
         d[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -497,7 +542,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           if (j == 1) acc = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            acc = __builtin_elementwise_fma(float4_t{w4[u], w4[u], w4[u], w4[u]}, v[u], acc);
+            acc = fma4(w4[u], v[u], acc);
         } else if (j == 3) {
           bf16x4 im[NS];
           split4n<NS>(acc, im);
@@ -546,13 +591,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
                 const int j = CT * jw + ct;
                 float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
                              *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
-                if (relu) {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
-                }
+                o = relu4(o, relu, floor_bits);
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
-                d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
               }
             }
           }
@@ -570,7 +611,19 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
             }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, d[ct][ti]);
+            for (int ct = 0; ct < CT; ++ct) {
+              // the first unit of a tile starts from a ZERO C operand (an inline constant of the MFMA) instead of
+              // re-zeroed accumulator registers: 32 moves per tile and wave less on the vector ALU
+              const f32x4 cin = (c == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
+              if constexpr (K8_ABL_NOWLO) {
+                bf16x8 wt[NS];
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) wt[s_] = bw[ct][ks][0];
+                d[ct][ti] = gwen::mma_split<8, NS>(wt, acur, cin);
+              } else {
+                d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, cin);
+              }
+            }
           });
           if (K8_PRIO) __builtin_amdgcn_s_setprio(0);
         };
@@ -632,13 +685,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
                 const int j = CT * jw + ct;
                 float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
                              *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
-                if (relu) {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.0f ? 0.0f : o[e];
-                }
+                o = relu4(o, relu, floor_bits);
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
-                d[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
               }
               n_ops += CT;
             }
@@ -662,7 +711,19 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
           }
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, d[ct][ti]);
+          for (int ct = 0; ct < CT; ++ct) {
+              // the first unit of a tile starts from a ZERO C operand (an inline constant of the MFMA) instead of
+              // re-zeroed accumulator registers: 32 moves per tile and wave less on the vector ALU
+              const f32x4 cin = (c == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
+              if constexpr (K8_ABL_NOWLO) {
+                bf16x8 wt[NS];
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) wt[s_] = bw[ct][ks][0];
+                d[ct][ti] = gwen::mma_split<8, NS>(wt, acur, cin);
+              } else {
+                d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, cin);
+              }
+            }
         }
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k)
@@ -790,7 +851,7 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
 #define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
 #define GWEN_W(FI, FO)                                                                                \
   if (Fin == FI && Fout == FO) {                                                                      \
-    constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
+    constexpr int NWV = FI >= 256 ? (K8_ABL_NOWLO ? 16 : 8) : 16;                                     \
     if constexpr (FI <= 128 || FO <= 128) {                                                           \
       if (x6) return launch<FI, FO, NWV, 1, 128, true, false, 3>(GWEN_ARGS);                          \
     }                                                                                                 \
