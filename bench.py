@@ -768,11 +768,12 @@ def main():
         line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x3")
         line["hbm_leg"]["default_precision_bf16x6"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto")
         # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache: K8 on both splits
+        # (same convention: the leg itself on precision "3xbf16", the library default nested beside it)
         line["hbm_leg_64ch"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
-                                       what="c2's width beyond the Infinity Cache", order="auto")
-        line["hbm_leg_64ch"]["bf16x3"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels,
-                                                 m=args.hbm_members_narrow,
-                                                 what="c2's width beyond the Infinity Cache", order="auto_x3")
+                                       what="c2's width beyond the Infinity Cache", order="auto_x3")
+        line["hbm_leg_64ch"]["default_precision_bf16x6"] = hbm_leg(
+            gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
+            what="c2's width beyond the Infinity Cache", order="auto")
 
     # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline

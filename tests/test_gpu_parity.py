@@ -685,3 +685,44 @@ def test_masked_l1_empty_mask_is_nan_like_torch(ga):
     o = torch.randn(64, 8, device=DEV)
     none = torch.zeros(64, dtype=torch.bool, device=DEV)
     assert torch.isnan(ga.loss_func(o, torch.zeros_like(o), none))
+
+
+def test_training_step_replays_from_a_hipgraph(ga):
+    """Forward + masked-L1 loss + backward + Adam of the reference's loop shape (models_gnn.py:362-373) captured ONCE
+    into a hipGraph and replayed: every launcher of libgwen_hip.so is capturable (no allocation, no synchronisation
+    inside), so a training step can leave the host's per-launch cost behind (tools/train_bench.py ... graph)."""
+    m = ga.geodesic_mesh(9, reorder="hilbert")
+    ei = torch.from_numpy(m.edge_index).to(DEV)
+    torch.manual_seed(SEED)
+    model = ga.GNNModel(ga.GNNConfig(1, 1, 16, 16, 32)).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True, capturable=True)
+    x = torch.randn(m.num_nodes, 16, device=DEV)
+    mask = torch.zeros(m.num_nodes, dtype=torch.bool, device=DEV); mask[::2] = True
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ga.loss_func(model(x, ei), x, mask)
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        loss = ga.loss_func(model(x, ei), x, mask)
+        loss.backward()
+        opt.step()
+    g.replay()
+    torch.cuda.synchronize()
+    first = float(loss.detach())
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    assert float(loss.detach()) < first

@@ -14,7 +14,7 @@ print("c2 ms/step", round(d["ms_per_step"], 4))
 for k in ("hbm_leg", "hbm_leg_64ch"):
     r = d[k]["roofline"]
     print(k, d[k]["contraction"][:6], r["kernel"], "avg us", r["avg_launch_us"], "frac", r["frac"], "ms/step", d[k]["ms_per_step"])
-    for kk in ("default_precision_bf16x6", "bf16x3"):
+    for kk in ("default_precision_bf16x6",):
         if kk in d[k]:
             r2 = d[k][kk]["roofline"]
             print("    ", kk, r2["kernel"], "avg us", r2["avg_launch_us"], "frac", r2["frac"])
