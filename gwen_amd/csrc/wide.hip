@@ -809,10 +809,10 @@ extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
 extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract) {
   if (!gwen_gcn_wide_supported(Fin, Fout)) return 0;
   if (contract == GWEN_CONTRACT_BF16X3) return 1;
-  // bf16x6 at 256 -> 256: three images of W are 192 of the 256 registers a wave has there -- hipcc spills 85-91 of
-  // them and the kernel runs 141-157 us per pass on one member against K4's 127 (measured): refused, the planner
-  // takes K4.  256 -> 64 / 128 hold half / a quarter of the columns per wave and fit.
-  return contract == GWEN_CONTRACT_BF16X6 && (Fin <= 128 || Fout <= 128) ? 1 : 0;
+  // bf16x6 at 256 -> 256: three images of W are 192 of the 256 registers a wave has there (hipcc spills 85-91 of
+  // them: 141-157 us per pass on one member against K4's 127, measured); 256 -> 64 / 128 hold half / a quarter of
+  // the columns per wave and fit, so 256 -> 256 runs as two 256 -> 128 launches (gwen_gcn_wide_layer_f32).
+  return contract == GWEN_CONTRACT_BF16X6 ? 1 : 0;
 }
 
 extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
@@ -848,6 +848,19 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
   const bool small_union = union_max <= 128;
   const bool x6 = contract == GWEN_CONTRACT_BF16X6;
   if (x6 && !small_union) return GWEN_ERANGE;
+  if (x6 && Fin == 256 && Fout == 256) {
+    // three images of W for all 256 output columns are 192 registers per wave; for 128 columns they fit.  The layer
+    // runs as TWO launches of the 256 -> 128 kernel, each staging and aggregating the rows again and writing its half
+    // of the output columns (row stride ldo): every output column still sums the same terms in the same order
+    // (bitwise K4's bf16x6), at about twice a 256 -> 128 pass instead of K4's gathers through L1
+    for (int half = 0; half < 2; ++half) {
+      const int rc = launch<256, 128, 8, 1, 128, true, false, 3>(
+          t_rows, t_lid, t_val, x, W + (int64_t)half * 128 * 256, bias ? bias + half * 128 : nullptr, out + half * 128,
+          N, ldo, members, mstride_x, mstride_o, relu, st);
+      if (rc != GWEN_OK) return rc;
+    }
+    return GWEN_OK;
+  }
 #define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
 #define GWEN_W(FI, FO)                                                                                \
   if (Fin == FI && Fout == FO) {                                                                      \

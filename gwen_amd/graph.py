@@ -134,14 +134,12 @@ class GraphCSR:
         start_old = self.rowptr[:-1].long().index_select(0, perm)
         within = torch.arange(nnz, device=dev) - new_rowptr[:-1].repeat_interleave(new_len)
         src_pos = start_old.repeat_interleave(new_len) + within           # old entry position of every new entry
-        pad = self.col.numel() - nnz                                       # keep the arrays' slack (vector reads)
-        col_p = torch.zeros_like(self.col)
+        col_p = torch.zeros_like(self.col)                                # same slack past the entries (vector reads)
         val_p = torch.zeros_like(self.val)
         eid_p = torch.full_like(self.eid, -1)
         col_p[:nnz] = inv.index_select(0, self.col[:nnz].long().index_select(0, src_pos)).to(torch.int32)
         val_p[:nnz] = self.val[:nnz].index_select(0, src_pos)
         eid_p[:nnz] = self.eid[:nnz].index_select(0, src_pos)
-        del pad
         gp = GraphCSR(n, self.num_edges, new_rowptr.to(torch.int32), col_p, val_p, eid_p,
                       self.dis.index_select(0, perm) if self.dis.numel() == n else self.dis, self.status)
         if gp.tiles() is None:

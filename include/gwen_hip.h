@@ -222,8 +222,9 @@ int gwen_gcn_tiles64(const int32_t *rowptr, const int32_t *col, const float *val
  * unpermuted kernels because every row still sums its entries in stored order. */
 int gwen_cluster_rows64_host(const int32_t *rowptr, const int32_t *col, int64_t N, int64_t N_src, int32_t *perm);
 int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout);
-/* contract: GWEN_CONTRACT_BF16X3 for every supported width pair; GWEN_CONTRACT_BF16X6 for every pair but
- * 256 -> 256 (three images of W exceed the registers of the 8 waves that hold them there: that layer runs on K4). */
+/* contract: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6 for every supported width pair (bf16x6 needs tile unions
+ * within 128 rows; at 256 -> 256 it runs as two 256 -> 128 launches: three images of W for all 256 output columns
+ * exceed the registers of the 8 waves that hold them). */
 int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract);
 /* 1 when an AUTO layer of these widths over N rows x members is issued as K8 rather than K4 (given a graph
  * that tiles): every supported width pair with Fin >= 128 (measured 1.15x - 1.6x K4), and Fin = 64 once the

@@ -104,9 +104,9 @@ def test_wide_equals_k4_bitwise_and_oracle(ga, cref, fin, fout, nu, reorder):
         ref = cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=relu, f64=True)
         assert rel_err(got, ref) <= 2e-5
     assert torch.equal(ops.wide_layer(g, xd, wd, None), ops.layer_fused(g, xd, wd, None))
-    # bf16x6 on K8: every width pair but 256 -> 256, on graphs whose unions stay within 128 rows; K4's bf16x6 bit for bit
+    # bf16x6 on K8: graphs whose unions stay within 128 rows; K4's bf16x6 bit for bit
     umax = g.tiles()[3]
-    if (fin <= 128 or fout <= 128) and umax <= 128:
+    if umax <= 128:            # (256 -> 256 runs as two 256 -> 128 launches: W's three images for 128 columns fit)
         got6 = ops.wide_layer(g, xd, wd, bd, relu=True, contract="bf16x6")
         assert torch.equal(got6, ops.layer_fused(g, xd, wd, bd, relu=True, contract="bf16x6")), (fin, fout)
         ref = cref.conv(x.numpy(), ei.numpy(), w.numpy(), b.numpy(), relu=True, f64=True)
