@@ -49,6 +49,9 @@
 #ifndef K8_ABL_NOWLO  // TIMING ABLATION (results wrong by construction): W's second image is not kept -- what would
 #define K8_ABL_NOWLO 0 // 16 waves at Fin = 256 buy if W's low image did not occupy registers?  (-DK8_ABL_NOWLO=1)
 #endif
+#ifndef K8_D          // chunks of DMA in flight behind the one being aggregated (bf16x3, unions <= 128 rows): 1, 2, or
+#define K8_D (-1)     // -1 = what measured fastest per width (2 at Fin = 64, 1 above)
+#endif
 #ifndef K8_NT_LD      // 1: non-temporal staging loads too (variant builds; measured: see glds16_p)
 #define K8_NT_LD 0
 #endif
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
     int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu, int32_t ldx, int nt) {
   // ROLES (below): the two waves of a SIMD take the step's two halves in opposite order
-  constexpr bool ROLES = (K8_ROLES < 0 ? FIN == 64 : K8_ROLES != 0) && !DENSE && D == 1;
+  constexpr bool ROLES = (K8_ROLES < 0 ? (FIN == 64 && D == 1) : K8_ROLES != 0) && !DENSE && (D == 1 || D == 2);
   constexpr int NSTG = D + 1;                           // stage buffers
   constexpr int kStageBytes = KU * kFC * 4;
   constexpr int NC = FIN / kFC;                         // chunks per tile
@@ -574,12 +577,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             row = mh == 3 ? r3 : row;
             const uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
             glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
+            ++n_ops;
           }
         }
         if (c2 == 0 && wave < 3) {
           const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t2 * (kRows * 32) + wave * 1024
                                      : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
+          ++n_ops;
         }
         auto half_y = [&]() {
           if (c == 0 && spread_stores) {
@@ -637,7 +642,11 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           __builtin_amdgcn_sched_barrier(0);
           half_x();
         }
-        young = 0;
+        // D = 2: the chunk the next wait is for is OLDER than everything this interval issued (its DMAs and the
+        // stores of half Y), so all of that may stay in flight; D = 1: that chunk is among them
+        if (c == 0 && spread_stores) n_ops += CT * NTT;
+        young = D == 2 ? n_ops : 0;
+        prev_ops = n_ops;
         sb = sb + 1 == NSTG ? 0 : sb + 1;
         return;
       }
@@ -838,11 +847,13 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
   if (N_src * Fin * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;     // 32-bit row offsets
   hipStream_t st = gwen_stream(stream_);
   // 16 waves where the registers allow (Fin <= 128), 8 at Fin = 256 (W alone is 128 registers there).
-  // One chunk of DMA in flight behind the chunk being aggregated (D = 1), issued in the first regions of a
-  // step.  A CU takes ~32 LDS-DMA wave instructions in flight before further issues stall (measured,
-  // tools/experiments/reads/glds.hip: 65 cycles per issue up to 32 outstanding, 200-500 beyond), so a second
-  // chunk in flight (D = 2, which unions <= 128 rows would leave LDS room for) only moves the wait into the
-  // issue: 246-252 us either way at 256 channels x 4 members.  Unions <= 128 rows stage 128 slots per chunk.
+  // Chunks of DMA in flight behind the chunk being aggregated: D = 1 from 128 channels up -- at 256 channels x 4
+  // members a second chunk in flight measures within +-1 % (236-240 us either way, round 3; 246-252 in round 2: a CU
+  // takes ~32 LDS-DMA wave instructions in flight before further issues stall, tools/experiments/reads/glds.hip) --
+  // and D = 2 at 64 channels on bf16x3, where a step is one whole tile and short: 64 -> 64 x 16 members 193.9 -> 185.5
+  // us in the 4-layer stack (A/B on one box; with the ROLES order of the halves on top: no further gain, so ROLES is
+  // for D = 1 -- i.e. bf16x6, whose third A image takes the third stage buffer's LDS).
+  // Unions <= 128 rows stage 128 slots per chunk.
   // bf16x6 keeps a third image of every A chunk: its LDS fits beside 128-slot stage buffers only, so unions
   // beyond 128 rows are refused (GWEN_ERANGE: the caller takes K4).
   const bool small_union = union_max <= 128;
@@ -868,7 +879,8 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
     if constexpr (FI <= 128 || FO <= 128) {                                                           \
       if (x6) return launch<FI, FO, NWV, 1, 128, true, false, 3>(GWEN_ARGS);                          \
     }                                                                                                 \
-    return small_union ? launch<FI, FO, NWV, 1, 128, true>(GWEN_ARGS)                                 \
+    constexpr int DV = K8_D > 0 ? K8_D : (FI == 64 ? 2 : 1);                                          \
+    return small_union ? launch<FI, FO, NWV, DV, 128, true>(GWEN_ARGS)                                \
                        : launch<FI, FO, NWV, 1, 192, true>(GWEN_ARGS);                                \
   }
   GWEN_W(64, 64); GWEN_W(64, 128); GWEN_W(64, 256);
