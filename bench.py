@@ -333,7 +333,11 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
     avg = tot / cnt
     comp = compulsory_bytes(kind, n, e, fin, fout, m)
     ws_mib = 2 * 4 * m * n * f / 2 ** 20
-    tags = kernel_tags(kind, fin, fout, 3 if order == "auto" else 2)
+    ns = 3 if order == "auto" else 2
+    tags = kernel_tags(kind, fin, fout, ns)
+    launches_per_layer = 1
+    if kind == "wide" and (fin, fout, ns) == (256, 256, 3):      # bf16x6 at 256 -> 256 = two 256 -> 128 launches
+        tags, launches_per_layer = kernel_tags(kind, 256, 128, 3), 2
     # one member against the CPU oracle's first layer would take minutes at this width; parity at this size
     # is tests/test_gpu_wide.py::test_c3_layer_at_config_size_four_members
     return {
@@ -347,7 +351,8 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
                      "achieved": round(comp / avg / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(comp / avg / 1e9 / HBM_PEAK_GBS, 4),
                      "compulsory_bytes_per_launch": comp, "avg_launch_us": round(avg * 1e6, 2),
-                     "samples": cnt, "traffic": pmc_traffic(tags),
+                     "samples": cnt,
+                     "traffic": (lambda v_: None if v_ is None else launches_per_layer * v_)(pmc_traffic(tags)),
                      "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                        "of this command, gfx950 corrections applied)",
                      "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2)

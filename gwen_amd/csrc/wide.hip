@@ -632,6 +632,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           });
           if (K8_PRIO) __builtin_amdgcn_s_setprio(0);
         };
+        // (with every row read of a half in flight instead of 4 at a time -- aggregate() -- the 256-channel kernel spills
+        //  52 registers: 389 us against 252; the lean form spills 20 there: 292 us.  ROLES is not for 256 channels.)
         auto half_x = [&]() { aggregate_lean(sb1, ab1, eb1); };
         if (wave < NW / 2) {
           half_x();
