@@ -265,3 +265,51 @@ def test_loss_func_index_mask_is_the_reference_expression():
     # a 0/1 integer vector of length N is an index tensor too (rows 0 and 1), not a row selector
     z = torch.zeros(20, dtype=torch.long); z[5] = 1
     assert float(gwen_amd.loss_func(o, t, z)) == float(torch.nn.functional.l1_loss(o[z], t[z]))
+
+
+def test_cluster_rows64_host_grows_compact_patches():
+    """gwen_cluster_rows64_host (csrc/cluster.hip) is host code: no GPU needed.  On a randomly relabelled geodesic
+    mesh (an unordered edge_index) it returns a permutation whose consecutive blocks of 64 rows name few distinct
+    sources -- what K8's tile layout needs (<= 192) -- where the caller's own numbering names hundreds."""
+    import ctypes as C
+    from gwen_amd import _lib, build
+    from gwen_amd.mesh import geodesic_mesh
+    build.build()
+    L = _lib.lib()
+    m = geodesic_mesh(30)
+    n = m.num_nodes
+    rng = np.random.default_rng(3)
+    relabel = rng.permutation(n)
+    ei = relabel[m.edge_index]
+    # CSR by target with the self-loop last, as K1 stores it
+    order = np.argsort(ei[1], kind="stable")
+    src, dst = ei[0][order], ei[1][order]
+    counts = np.bincount(dst, minlength=n) + 1
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(counts)
+    col = np.empty(int(rowptr[-1]), dtype=np.int32)
+    fill = rowptr[:-1].copy()
+    for s_, d_ in zip(src, dst):
+        col[fill[d_]] = s_
+        fill[d_] += 1
+    col[fill] = np.arange(n, dtype=np.int32)                     # the completed self-loops
+
+    def worst_union(perm):
+        worst = 0
+        for t in range(0, n, 64):
+            rows = perm[t:t + 64]
+            srcs = np.unique(np.concatenate([col[rowptr[r]:rowptr[r + 1]] for r in rows]))
+            worst = max(worst, len(srcs))
+        return worst
+
+    perm = np.empty(n, dtype=np.int32)
+    rc = L.gwen_cluster_rows64_host(rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n, n,
+                                    perm.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert np.array_equal(np.sort(perm), np.arange(n))           # a permutation
+    assert worst_union(np.arange(n)) > 192                       # the caller's numbering does not tile
+    assert worst_union(perm) <= 192                              # the grown order does
+    # rectangular graphs are refused, an empty graph is fine
+    assert L.gwen_cluster_rows64_host(rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n, n + 1,
+                                      perm.ctypes.data_as(C.c_void_p)) != 0
+    assert L.gwen_cluster_rows64_host(None, None, 0, 0, None) == 0
