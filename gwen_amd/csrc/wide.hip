@@ -52,6 +52,9 @@
 #ifndef K8_D          // chunks of DMA in flight behind the one being aggregated (bf16x3, unions <= 128 rows): 1, 2, or
 #define K8_D (-1)     // -1 = what measured fastest per width (2 at Fin = 64, 1 above)
 #endif
+#ifndef K8_D6         // the same for bf16x6 (two chunks need the 144-B A pitch to fit the LDS): -1 = 2 at Fin = 64, 1 above
+#define K8_D6 (-1)
+#endif
 #ifndef K8_NT_LD      // 1: non-temporal staging loads too (variant builds; measured: see glds16_p)
 #define K8_NT_LD 0
 #endif
@@ -71,12 +74,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRows = GWEN_TILE_ROWS;        // 64 destination rows per tile
 constexpr int kUCap = GWEN_TILE_UNION;       // 192 union slots per tile in t_rows
 constexpr int kFC = 64;                      // features per chunk
-constexpr int kPB = 80;                      // A-chunk row pitch in bf16 (160 B: conflict-free 16-B reads)
-constexpr int kAImg = kRows * kPB * 2;       // one bf16 image of a chunk: 10240 B
+// A-chunk row pitch in bf16: 80 (160 B: conflict-free 16-B fragment reads); 72 (144 B: two-way conflicts on a third
+// of the fragment reads) where three images AND a third stage buffer must share the CU's 160 KiB -- bf16x6 with two
+// chunks of DMA in flight, i.e. 64 channels, where a wave reads 6 fragments per tile and the conflicts do not show
+constexpr int pitch_a(int ns, int d) { return ns == 3 && d == 2 ? 72 : 80; }
 constexpr int kEntBytes = kRows * 8 * 4 + kRows * 8 * 2;   // weights fp32 + local ids u16 = 3072
 // LDS of one block: (D + 1) stage buffers of KU slots x 256 B | 2 A chunks of NS images | 3 entry sets | bias
 constexpr int lds_bytes(int nstg, int ku, int ns) {
-  return nstg * ku * kFC * 4 + 2 * ns * kAImg + 3 * kEntBytes + 1024;
+  return nstg * ku * kFC * 4 + 2 * ns * (kRows * pitch_a(ns, nstg - 1) * 2) + 3 * kEntBytes + 1024;
 }
 
 // aggregated rows -> NS bf16 images (split.h)
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   constexpr int NP = kRows / (4 * NW);                  // aggregate passes per wave and chunk
   static_assert(NC >= 1 && 4 % TSTEP == 0 && (NJ % NW == 0 || NW % NJ == 0), "unsupported widths");
   static_assert(NQ * 4 * NW == KU && NP * 4 * NW == kRows, "waves must tile the union and the rows");
+  constexpr int kPB = pitch_a(NS, D), kAImg = kRows * kPB * 2;     // one bf16 image of a chunk: 10240 B (9216)
   constexpr int kABytes = NS * kAImg;                   // one A chunk: NS images
   constexpr int kOffStage = 0, kOffA = NSTG * kStageBytes, kOffEnt = kOffA + 2 * kABytes;
   constexpr int kOffBias = kOffEnt + 3 * kEntBytes, kLds = lds_bytes(NSTG, KU, NS);
@@ -879,7 +885,8 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
   if (Fin == FI && Fout == FO) {                                                                      \
     constexpr int NWV = FI >= 256 ? (K8_ABL_NOWLO ? 16 : 8) : 16;                                     \
     if constexpr (FI <= 128 || FO <= 128) {                                                           \
-      if (x6) return launch<FI, FO, NWV, 1, 128, true, false, 3>(GWEN_ARGS);                          \
+      constexpr int D6 = K8_D6 > 0 ? K8_D6 : (FI == 64 ? 2 : 1);                                      \
+      if (x6) return launch<FI, FO, NWV, D6, 128, true, false, 3>(GWEN_ARGS);                         \
     }                                                                                                 \
     constexpr int DV = K8_D > 0 ? K8_D : (FI == 64 ? 2 : 1);                                          \
     return small_union ? launch<FI, FO, NWV, DV, 128, true>(GWEN_ARGS)                                \
