@@ -62,6 +62,12 @@ def test_small_layer_vs_oracle(ga, name, n, ei, fin, fout, members, relu, use_bi
     again = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu, packed=img)
     assert rel_err(got.view(members, n, fout), want) <= 2e-5
     assert img.numel() == w.numel() * 4 and torch.equal(got, again)
+    # bf16x6 (the default precision of the host API): fp32-class; the packed images are bf16x3's and are not used
+    got6 = ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu, contract="bf16x6")
+    e6, e3 = rel_err(got6.view(members, n, fout), want), rel_err(got.view(members, n, fout), want)
+    assert e6 <= 5e-6 and e6 <= e3 + 1e-7          # fp32 accumulation over K up to 8192 is what is left
+    assert torch.equal(got6, ops.small_layer(graph, xs, w.to(DEV), b.to(DEV) if use_bias else None, relu, packed=img,
+                                             contract="bf16x6"))
 
 
 @pytest.mark.parametrize("n,c,h", [(125, 2048, 256), (150, 4096, 512)])
