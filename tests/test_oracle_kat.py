@@ -143,3 +143,33 @@ def test_model_composition_matches_manual_chain():
             t = torch.relu(t)
     assert torch.equal(t, m(x, ei))
     assert len(sd) == 20
+
+
+def test_dense_matrix_form_of_the_published_rule():
+    """A third, independent statement of the rule the oracle restates -- Kipf & Welling's
+    X' = D^-1/2 (A + I) D^-1/2 X W^T + b with A_ij = number of edges j -> i -- as dense fp64 matrix algebra (numpy),
+    against the op-sequence oracle on simple graphs, multigraphs (parallel edges count twice) and graphs that already
+    carry self-loops (de-duplicated to one loop of weight 1).  Anchors the oracle to the published formula rather
+    than to its own implementation (the reference holds no numeric fixture: SURVEY 8c)."""
+    import numpy as np
+    from helpers import random_multigraph
+    from gwen_amd.mesh import geodesic_mesh
+    rng = np.random.default_rng(5)
+    cases = [("mesh", geodesic_mesh(3).num_nodes, torch.from_numpy(geodesic_mesh(3).edge_index)),
+             ("multi", 60, random_multigraph(60, 400, self_loops=9, dup=30, isolate=3)),
+             ("path", 3, torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]]))]
+    for name, n, ei in cases:
+        fin, fout = 5, 7
+        x = rng.standard_normal((n, fin))
+        w = rng.standard_normal((fout, fin))
+        b = rng.standard_normal(fout)
+        a = np.zeros((n, n))
+        for s, d in ei.t().tolist():
+            if s != d:
+                a[d, s] += 1.0                      # parallel edges add up; explicit loops are dropped ...
+        a += np.eye(n)                              # ... and every node gets exactly one loop of weight 1
+        deg = a.sum(axis=1)                         # in-degree over targets, loop included
+        dis = 1.0 / np.sqrt(deg)
+        want = (dis[:, None] * a * dis[None, :]) @ x @ w.T + b
+        got = O.gcn_conv(torch.from_numpy(x), ei, torch.from_numpy(w), torch.from_numpy(b)).numpy()
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12), name
