@@ -726,3 +726,31 @@ def test_training_step_replays_from_a_hipgraph(ga):
         g.replay()
     torch.cuda.synchronize()
     assert float(loss.detach()) < first
+
+
+@pytest.mark.parametrize("contract", ["bf16x6", "3xbf16"])
+def test_split_contractions_are_scale_free(ga, contract):
+    """bf16 keeps fp32's exponent range, so the split contractions need no scaling: multiplying the input by a power
+    of two (far from overflow / underflow) scales every image, every product and every partial sum by exactly that
+    power -- the output is bitwise the scaled output.  (An fp16 split would not have this property.)"""
+    from gwen_amd import ops
+    m = ga.geodesic_mesh(6, reorder="hilbert")
+    n = m.num_nodes
+    g = ga.prepare_graph(torch.from_numpy(m.edge_index).to(DEV), n)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(SEED)).to(DEV)
+    w, _ = make_params(64, 64)
+    w = w.to(DEV)
+    base = ops.layer_fused(g, x, w, None, relu=True, contract=contract)
+    for p in (40, -40, 90, -90):
+        s = 2.0 ** p
+        got = ops.layer_fused(g, x * s, w, None, relu=True, contract=contract)
+        assert torch.equal(got, base * s), p
+        lin = ops.linear(x * s, w, contract=contract)
+        assert torch.equal(lin, ops.linear(x, w, contract=contract) * s), p
+    # non-finite inputs stay visible: a NaN or Inf in a row reaches that row's outputs (and its neighbours')
+    xb = x.clone()
+    xb[5, 3] = float("nan")
+    xb[9, 7] = float("inf")
+    out = ops.layer_fused(g, xb, w, None, relu=False, contract=contract)
+    assert not torch.isfinite(out[5]).any() and not torch.isfinite(out[9]).any()
+    assert torch.isfinite(out).any()
