@@ -106,6 +106,10 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:       # python -m gwen_amd.build --variant NAME [--src a.hip,b.hip] -DX=1 ...
         i = sys.argv.index("--variant")
         srcs = sys.argv[sys.argv.index("--src") + 1].split(",") if "--src" in sys.argv else None
-        print(build_variant(sys.argv[i + 1], [a for a in sys.argv if a.startswith(("-D", "-f", "-m"))], srcs, verbose=True))
+        extra, args = [], sys.argv[1:]
+        for k, a in enumerate(args):                      # -D / -f / -m flags, and the value of every "-mllvm"
+            if a.startswith(("-D", "-f", "-m")) or (k > 0 and args[k - 1] == "-mllvm"):
+                extra.append(a)
+        print(build_variant(sys.argv[i + 1], extra, srcs, verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -61,8 +61,50 @@
 #ifndef K8_LD_POLICY  // experiment: cache policy of the staging DMAs (" nt", " sc1", ...)
 #define K8_LD_POLICY ""
 #endif
+#ifndef K8_SHIFT      // 1: the vector work of an aggregate stage runs ONE REGION AFTER the stage's LDS reads (two row
+#define K8_SHIFT 1    // buffers), so the reads' latency sits behind a region of MFMAs instead of in front of the first woven fma
+#endif
+#ifndef K8_AFRAG_FIRST
+#define K8_AFRAG_FIRST 0   // measured: no gain at 256 channels (229-231 vs 226-229 us), the weave loses its shape
+#endif
+#ifndef K8_BFRAG
+#define K8_BFRAG 0         // measured: 64 -> 64 x 16 members 180.6 -> 186.5 us, 256 x 4 within noise (and 4-9 spills)
+#endif
+#ifndef K8_STAMP      // DIAGNOSTIC build (-DK8_STAMP=1, tools/experiments/k8_stamp.py): block K8_STAMP_BLOCK's waves record
+#define K8_STAMP 0    // s_memtime at five points of 32 steps into LDS and dump them to gwen_k8_stamp_buf at the end
+#endif
+#ifndef K8_STAMP_BLOCK
+#define K8_STAMP_BLOCK 9
+#endif
+#ifndef K8_ABL_NOSTORE  // TIMING ABLATION (no output): what do the spread stores of a finished tile cost the step they ride in?
+#define K8_ABL_NOSTORE 0
+#endif
+#ifndef K8_ABL_STORE_LOCAL
+#define K8_ABL_STORE_LOCAL 0
+#endif
+#ifndef K8_LATE0      // 1 (with two chunks in flight): the step that stores a tile issues its DMAs in its LAST regions, behind the stores
+#define K8_LATE0 0
+#endif
+#ifndef K8_SKEW       // 1: at 4 chunks per tile, row tile t of a tile runs t steps behind row tile 0 (its A slices wait in a
+#define K8_SKEW 1     // ring), so ONE row tile finishes per step and the output stores are spread over every step
+#endif
+#ifndef K8_STAG       // 1: SKEW's stores dealt over the last four regions by wave instead of regions 5 and 7 for all
+#define K8_STAG 0
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
+#endif
+
+#if K8_STAMP
+__device__ uint32_t gwen_k8_stamp_buf[16 * 32 * 8];       // [wave][step][point]
+extern "C" int gwen_k8_stamps_read(uint32_t *host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gwen_k8_stamp_buf), sizeof(gwen_k8_stamp_buf));
+}
+// (waited for inside the statement: hipcc takes the output as written at once, and a result landing later would clobber
+//  whatever the register pair holds by then -- a pointer, once the stamps push the kernel past its SGPR budget)
+#define K8_TS(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[k]) :: "memory")
+#else
+#define K8_TS(k)
 #endif
 
 namespace {
@@ -208,9 +250,22 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   static_assert(NQ * 4 * NW == KU && NP * 4 * NW == kRows, "waves must tile the union and the rows");
   constexpr int kPB = pitch_a(NS, D), kAImg = kRows * kPB * 2;     // one bf16 image of a chunk: 10240 B (9216)
   constexpr int kABytes = NS * kAImg;                   // one A chunk: NS images
-  constexpr int kOffStage = 0, kOffA = NSTG * kStageBytes, kOffEnt = kOffA + 2 * kABytes;
-  constexpr int kOffBias = kOffEnt + 3 * kEntBytes, kLds = lds_bytes(NSTG, KU, NS);
+  // SKEW (Fin = 256 -> 128 / 256, bf16x3, unions <= 128 rows): the matrix work of row tile t on chunk s' runs in step
+  // s' + t, so that row tile t of a tile is complete -- and stored, two instructions per wave -- in step (t + 3) % 4 + 1
+  // of the stream instead of all four row tiles (8 instructions per wave, 64 KiB per CU) in the tile's last step.
+  // Measured before: the step that carried a tile's stores ran 4 600 cycles of regions against 1 400 for the others
+  // (in-kernel stamps), and a build that stored nothing ran 167 us against 234 (256 -> 256 x 4 members): a CU drains
+  // stores at ~32 GB/s and the in-order waves stand behind them.  The aggregate of a chunk is kept per ROW TILE in a
+  // ring of t + 2 slices (written in step s' - 1, read in step s' + t): 14 slices of 5 KiB instead of 2 chunks of 20.
+  constexpr bool SKEW = K8_SKEW && !DENSE && !ROLES && NC == 4 && NTT == 4 && TSTEP == 1 && NS == 2 && D == 1 && KU == 128;
+  constexpr int kSlImg = 16 * kPB * 2, kSl = NS * kSlImg;        // one image / all images of a row tile's slice of a chunk
+  constexpr int kImgStride = SKEW ? kSlImg : kAImg;
+  constexpr int kOffStage = 0, kOffA = NSTG * kStageBytes, kOffEnt = kOffA + (SKEW ? 14 * kSl : 2 * kABytes);
+  constexpr int kOffBias = kOffEnt + 3 * kEntBytes, kLds = kOffBias + 1024;
+  static_assert(SKEW || kLds == lds_bytes(NSTG, KU, NS), "LDS layout");
+  auto ring_base = [](int ti) { return (ti * (ti + 3) / 2) * kSl; };     // rings of 2, 3, 4, 5 slices: first slice 0, 2, 5, 9
   static_assert(kLds <= 160 * 1024, "the block's LDS exceeds a CU's");
+  constexpr int kStampBytes = K8_STAMP && kLds + NW * 1024 <= 160 * 1024 ? NW * 1024 : 0;   // (diagnostic build, where it fits)
   static_assert(!DENSE || KU == kRows, "a dense tile stages its own rows");
   const uint32_t row_pitch = DENSE ? (uint32_t)ldx * 4u : (uint32_t)(FIN * 4);
   const int floor_bits = relu ? 0 : (int)0x80000000;     // relu4
@@ -218,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     if (nt && K8_NT_LD) glds16_p<true>(base, voff, dst);
     else glds16_p<false>(base, voff, dst);
   };
-  __shared__ __attribute__((aligned(1024))) char lds[kLds];
+  __shared__ __attribute__((aligned(1024))) char lds[kLds + kStampBytes];
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int mi = lane & 15, mh = lane >> 4;
@@ -378,8 +433,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       bf16x4 im[NS];
       split4n<NS>(acc[p], im);
       char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
+      if constexpr (SKEW)                               // (the prologue's chunk 0: slot 0 of the row tile's ring)
+        a = lds + kOffA + ring_base(2 * p + (wave >> 2)) + ((lr & 15) * kPB + mi * 4) * 2;
 #pragma unroll
-      for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
+      for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kImgStride) = im[s_];
     }
   };
 
@@ -477,6 +534,12 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   int eb = 0;                 // i % 3
   int young = 0;              // operations that may stay in flight at the next wait
   int prev_ops = 0;           // what the interval before this one issued (D = 3)
+#if K8_STAG
+  const int sreg0 = NU - 4 + (wave & 3), sreg1 = NU - 4 + ((wave + 2) & 3);      // SKEW: store regions by wave (variant build)
+#else
+  constexpr int sreg0 = CT == 1 ? NU - 2 : NU - 3, sreg1 = NU - 1;               // SKEW: the step's store regions
+#endif
+  int rd0 = 0, rd1 = 2, rd2 = 2, rd3 = 2;   // SKEW: ring slot row tile t READS in this step = (s - t) mod (t + 2); it writes the slot before
   for (int i = 0; i < ntl; ++i) {
     gwen_static_for<NC>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
@@ -495,14 +558,52 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
           for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
       }
+      // the bias fragments of this wave's columns, read ahead of the barrier in the step that stores a tile (a read in
+      // front of every store waits a full LDS round trip before the region's MFMAs: 8 of them per tile)
+      const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
+      float4_t bfrag[CT];
+      if (c == 0 && K8_BFRAG) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bfrag[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+      }
+#if K8_STAMP
+      uint64_t ts[5] = {0, 0, 0, 0, 0};
+#endif
+      K8_TS(0);
       wait_vmcnt(young);
+      K8_TS(1);
       __syncthreads();
+      K8_TS(2);
       int n_ops = 0;
       // ---- stores of tile i-1: a tile whose 64 rows all exist is stored region by region with every lane
       // active (exact instruction counts for the waits); the last tile of a member at once, guarded, drained
       bool spread_stores = false;
       float *obase = nullptr;                             // this lane's first output element of the tile
-      if (c == 0 && i > 0) {
+      // SKEW: the step's units run row tile (c + 1) % 4 FIRST -- the one on its tile's last chunk: complete after region 1,
+      // stored in this step's LATE regions (its next tile starts in the LAST regions of the next step).  Tile i's row tile 0
+      // completes in step 3, row tiles 1 .. 3 of tile i - 1 in steps 0 .. 2.
+      constexpr int tfin = (c + 1) & 3;
+      float *srow = nullptr;
+      bool s_any = false, s_whole = false, s_ok = false;
+      if (SKEW && (c == 3 || i > 0)) {
+        int ms, ts;
+        split_tile(tile_of(c == 3 ? i : i - 1), ms, ts);
+        const int r = ts * kRows + tfin * 16 + mi;
+        s_any = true;
+        s_whole = (ts + 1) * kRows <= N;
+        s_ok = r < N;
+        srow = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
+        if (K8_ABL_STORE_LOCAL)       // TIMING ABLATION: every block rewrites its own 64 rows (cache-resident): no HBM writes
+          srow = out + (int64_t)(blockIdx.x * kRows + tfin * 16 + mi) * ldo + (CT * jw * 16 + 4 * mh);
+      }
+      int late_ops = 0;                                   // SKEW: stores issued behind the step's last DMA (they may stay in flight)
+      int aw0 = 0, aw1 = 0;                               // SKEW: where this step's two aggregate passes write (byte offset in A)
+      if constexpr (SKEW) {
+        const int w0 = rd0 == 0 ? 1 : rd0 - 1, w1 = rd1 == 0 ? 2 : rd1 - 1, w2 = rd2 == 0 ? 3 : rd2 - 1, w3 = rd3 == 0 ? 4 : rd3 - 1;
+        aw0 = (wave >> 2) ? ring_base(1) + w1 * kSl : ring_base(0) + w0 * kSl;
+        aw1 = (wave >> 2) ? ring_base(3) + w3 * kSl : ring_base(2) + w2 * kSl;
+      }
+      if (!SKEW && c == 0 && i > 0) {
         int ms, ts;
         split_tile(tile_of(i - 1), ms, ts);
         if ((ts + 1) * kRows <= N) {
@@ -513,7 +614,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           store_tile(tile_of(i - 1));                   // drains
         }
       }
-      const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
       // ---- aggregate(s+1) state -------------------------------------------------------------------------------
       constexpr int a1 = c + 1;
       const int sb1 = sb + 1 == NSTG ? 0 : sb + 1, ab1 = (s + 1) & 1, eb1 = (eb + a1 / NC) % 3;
@@ -521,10 +621,16 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       const char *stg = lds + kOffStage + sb1 * kStageBytes + mi * 16;
       u32x4 lid4 = {0, 0, 0, 0};
       float4_t wa = {0.f, 0.f, 0.f, 0.f}, wb = wa, acc = wa;
-      float4_t v[4];
+      // SHIFT: stage k's vector work is issued in the region AFTER its LDS reads (the last stage's in the last region),
+      // the two halves of a row's entries landing in two register buffers; without it (one buffer) a region's fma
+      // chains wait for the reads issued at its own start: ~150-250 cycles of LDS latency in front of the region's MFMAs
+      constexpr bool SHIFT = K8_SHIFT && !DENSE && NSTAGE == NU && NU >= 4 && !(NS == 3 && NW == 16);   // (128-register waves: bf16x6 would spill)
+      constexpr int NVB = SHIFT ? 2 : 1;
+      float4_t vbuf[NVB][4];
       auto stage_loads = [&](int k) {                   // k = 4 pass + stage
         const int p = k >> 2, j = k & 3;
         const int lr = 4 * NW * p + 4 * wave + mh;
+        float4_t (&v)[4] = vbuf[SHIFT && j == 2 ? NVB - 1 : 0];
         if constexpr (DENSE) {
           if (j == 1) v[0] = *reinterpret_cast<const float4_t *>(stg + lr * (kFC * 4));
         } else if (j == 0) {
@@ -543,6 +649,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       auto stage_valu = [&](int k) {
         const int p = k >> 2, j = k & 3;
         const int lr = 4 * NW * p + 4 * wave + mh;
+        float4_t (&v)[4] = vbuf[SHIFT && j == 2 ? NVB - 1 : 0];
         if constexpr (DENSE) {
           if (j == 1) acc = v[0];
         }
@@ -556,16 +663,22 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           bf16x4 im[NS];
           split4n<NS>(acc, im);
           char *a = lds + kOffA + ab1 * kABytes + (lr * kPB + mi * 4) * 2;
+          if constexpr (SKEW) a = lds + kOffA + (p == 0 ? aw0 : aw1) + ((lr & 15) * kPB + mi * 4) * 2;
 #pragma unroll
-          for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
+          for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kImgStride) = im[s_];
         }
       };
       const char *abase = lds + kOffA + (s & 1) * kABytes;
+      // first image of the A fragment of unit (row tile ti, k-step k2 of its chunk)
+      auto a_src = [&](int ti, int k2) -> const char * {
+        if constexpr (SKEW) return lds + kOffA + ring_base(ti) + (ti == 0 ? rd0 : ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2 + k2 * 64;
+        else return abase + (((tt0 + ti * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + k2 * 64;
+      };
       bf16x8 afrag[NS];                                   // A fragments (NS images) of the unit about to run
       {
-        const char *ap = abase + ((tt0 * 16 + mi) * kPB + 8 * mh) * 2;
+        const char *ap = a_src(SKEW ? ((c + 1) & 3) : 0, 0);
 #pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
+        for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
       }
       if constexpr (ROLES) {
         // ---- ROLES: every DMA of chunk s+2 first, then the step's two halves -- X = aggregate(s+1) (LDS reads,
@@ -599,9 +712,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) {
-                const int j = CT * jw + ct;
-                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
-                             *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
+                if (!K8_BFRAG) bfrag[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} + bfrag[ct];
                 o = relu4(o, relu, floor_bits);
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
@@ -664,7 +776,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         // memory instructions of this region
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          if ((EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
+          constexpr bool late = K8_LATE0 && D == 2 && c == 0 && NQ <= NU;
+          if ((late ? NU - NQ + q : EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
           if constexpr (DENSE) {
             int32_t row = t2 * kRows + 4 * (NW * q + wave) + mh;
             row = row < N ? row : N - 1;
@@ -685,11 +798,35 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             ++n_ops;
           }
         }
-        if (!DENSE && u == NU - 1 && c2 == 0 && wave < 3) {
+        if (!DENSE && u == (SKEW ? 3 : NU - 1) && c2 == 0 && wave < 3) {     // (SKEW: no DMA behind region 3, the late stores are counted)
           const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t2 * (kRows * 32) + wave * 1024
                                      : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
+        }
+        if constexpr (SKEW && u >= NU - 4) {
+          // the stores of the row tile that completed in region 1, BEHIND the step's DMAs (regions 0 .. 3).  A CU takes ~58
+          // cycles per store INSTRUCTION whatever its width (tools/experiments/stores/stwave.hip), one at a time, and a
+          // wave whose next memory instruction meets stores in the queue stands behind them.  (Dealing the 8 x CT stores
+          // over regions 2 .. 7 by wave, among the DMAs, measured slower: 225-227 against 222-223 us on one box.)
+          if (s_any) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              if ((ct == 0 ? sreg0 : sreg1) != u) continue;          // (wave-uniform: a scalar branch)
+              float4_t o = float4_t{d[ct][tfin][0], d[ct][tfin][1], d[ct][tfin][2], d[ct][tfin][3]} +
+                           *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+              o = relu4(o, relu, floor_bits);
+              if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
+              float4_t *dst = reinterpret_cast<float4_t *>(srow + ct * 16);
+              if (s_whole) {                                 // every lane stores: exactly one instruction (the waits count)
+                if (nt) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
+                ++late_ops;                                  // behind the wave's last DMA (region 3)
+              } else if (s_ok) {
+                *dst = o;
+              }
+            }
+          }
         }
         if (c == 0) {
 #pragma unroll
@@ -699,14 +836,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) {
-                const int j = CT * jw + ct;
-                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
-                             *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
+                if (!K8_BFRAG) bfrag[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} + bfrag[ct];
                 o = relu4(o, relu, floor_bits);
+                if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
               }
-              n_ops += CT;
+              n_ops += K8_ABL_NOSTORE ? 0 : CT;
             }
           }
         }
@@ -717,21 +854,24 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         {
           // the unit's A fragments were read one region earlier (their LDS latency sits behind that region's
           // MFMAs); the next unit's are requested now
-          constexpr int ti = u >> 1, k2 = u & 1, ks = 2 * c + k2;
+          constexpr int k2 = u & 1;
+          constexpr int ti = SKEW ? (((u >> 1) + c + 1) & 3) : (u >> 1);     // SKEW: the completing row tile first
+          constexpr int cu = SKEW ? ((c - ti) & 3) : c;          // the chunk (of ITS tile) row tile ti works on in this step
+          constexpr int ks = 2 * cu + k2;
           bf16x8 acur[NS];
 #pragma unroll
           for (int s_ = 0; s_ < NS; ++s_) acur[s_] = afrag[s_];
           if constexpr (u + 1 < NU) {
-            constexpr int tn = (u + 1) >> 1, kn = (u + 1) & 1;
-            const char *ap = abase + (((tt0 + tn * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + kn * 64;
+            constexpr int tn = SKEW ? ((((u + 1) >> 1) + c + 1) & 3) : ((u + 1) >> 1), kn = (u + 1) & 1;
+            const char *ap = a_src(tn, kn);
 #pragma unroll
-            for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kAImg);
+            for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
           }
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
               // the first unit of a tile starts from a ZERO C operand (an inline constant of the MFMA) instead of
               // re-zeroed accumulator registers: 32 moves per tile and wave less on the vector ALU
-              const f32x4 cin = (c == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
+              const f32x4 cin = (cu == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
               if constexpr (K8_ABL_NOWLO) {
                 bf16x8 wt[NS];
 #pragma unroll
@@ -743,24 +883,93 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             }
         }
 #pragma unroll
-        for (int k = 0; k < NSTAGE; ++k)
-          if (k * NU / NSTAGE == u) stage_valu(k);
+        for (int k = 0; k < NSTAGE; ++k) {
+          const int rl = k * NU / NSTAGE, rv = SHIFT ? (rl + 1 < NU ? rl + 1 : NU - 1) : rl;
+          if (rv == u) stage_valu(k);
+        }
+        // the next unit's A fragments are requested FIRST (left to itself hipcc sinks the reads behind the region's
+        // fifth MFMA, and the next region's first MFMA then waits for them: an LDS round trip in front of every region)
+        if constexpr (u + 1 < NU && K8_AFRAG_FIRST) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
 #pragma unroll
         for (int k = 0; k < CT * (NS == 2 ? 3 : 6); ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, WEAVE_VALU, 0);     // a few VALU instructions behind it
         }
+#if K8_STAMP
+        if constexpr (u == NU / 2 - 1) { __builtin_amdgcn_sched_barrier(0); K8_TS(3); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (u == NU - 1) { __builtin_amdgcn_sched_barrier(0); K8_TS(4); __builtin_amdgcn_sched_barrier(0); }
+#endif
       });
+#if K8_STAMP
+      {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rel = s - 2 * NC;                              // steps of tiles 2 .. : 32 of them
+        if (kStampBytes > 0 && blockIdx.x == K8_STAMP_BLOCK && rel >= 0 && rel < 32 && lane < 5) {
+          uint32_t tv = (uint32_t)ts[0];
+          tv = lane == 1 ? (uint32_t)ts[1] : tv;
+          tv = lane == 2 ? (uint32_t)ts[2] : tv;
+          tv = lane == 3 ? (uint32_t)ts[3] : tv;
+          tv = lane == 4 ? (uint32_t)ts[4] : tv;
+          reinterpret_cast<uint32_t *>(lds + kLds)[(wave * 32 + rel) * 8 + lane] = tv;
+        }
+      }
+#endif
       // what may stay in flight at the next wait: with two chunks of DMA in flight, everything this interval
       // issued (the DMA the next wait is for is older); with one, nothing (that DMA is among them)
       young = D == 3 ? n_ops + prev_ops : D == 2 ? n_ops : 0;
       prev_ops = n_ops;
       sb = sb + 1 == NSTG ? 0 : sb + 1;
+      if constexpr (SKEW) {
+        young = s_whole ? late_ops : 0;                   // (a guarded store may not have issued: wait for everything)
+        rd0 = rd0 == 1 ? 0 : rd0 + 1; rd1 = rd1 == 2 ? 0 : rd1 + 1; rd2 = rd2 == 3 ? 0 : rd2 + 1; rd3 = rd3 == 4 ? 0 : rd3 + 1;
+      }
     });
     eb = eb + 1 == 3 ? 0 : eb + 1;
   }
-  store_tile(tile_of(ntl - 1));
+  if constexpr (SKEW) {
+    // ---- drain: row tiles 1 .. 3 of the last tile are 1 .. 3 chunks behind: three more steps of matrix work only (their
+    // A slices were written before the last barrier), each completing and storing one row tile ----
+    int ms, ts;
+    split_tile(tile_of(ntl - 1), ms, ts);
+    const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
+    auto store_rt = [&](int rt) {
+      const int r = ts * kRows + rt * 16 + mi;
+      float *row = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        float4_t o = float4_t{d[ct][rt][0], d[ct][rt][1], d[ct][rt][2], d[ct][rt][3]} +
+                     *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+        o = relu4(o, relu, floor_bits);
+        if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
+        if (r < N) *reinterpret_cast<float4_t *>(row + ct * 16) = o;
+      }
+    };
+    gwen_static_for<3>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      gwen_static_for<3 - c>([&](auto tt) {
+        constexpr int ti = c + 1 + decltype(tt)::value, cu = (c - ti) & 3;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const char *ap = lds + kOffA + ring_base(ti) + (ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2 + k2 * 64;
+          bf16x8 af[NS];
+#pragma unroll
+          for (int s_ = 0; s_ < NS; ++s_) af[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][2 * cu + k2], af, d[ct][ti]);
+        }
+      });
+      store_rt(c + 1);                                  // on its last chunk in this step
+      rd0 = rd0 == 1 ? 0 : rd0 + 1; rd1 = rd1 == 2 ? 0 : rd1 + 1; rd2 = rd2 == 3 ? 0 : rd2 + 1; rd3 = rd3 == 4 ? 0 : rd3 + 1;
+    });
+  } else {
+    store_tile(tile_of(ntl - 1));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
+#if K8_STAMP
+  __syncthreads();
+  if (kStampBytes > 0 && blockIdx.x == K8_STAMP_BLOCK)
+    for (int k = threadIdx.x; k < NW * 32 * 8; k += NW * 64) gwen_k8_stamp_buf[k] = reinterpret_cast<uint32_t *>(lds + kLds)[k];
+#endif
 }
 
 template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false, int NS = 2>
