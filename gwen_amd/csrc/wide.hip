@@ -91,6 +91,18 @@
 #ifndef K8_STAG       // 1: SKEW's stores dealt over the last four regions by wave instead of regions 5 and 7 for all
 #define K8_STAG 0
 #endif
+#ifndef K8_SREG0      // SKEW: the regions of a step's two stores, and DMAs per region from region 0 on
+#define K8_SREG0 5
+#endif
+#ifndef K8_SREG1
+#define K8_SREG1 7
+#endif
+#ifndef K8_SKEW_DPR
+#define K8_SKEW_DPR 1
+#endif
+#ifndef K8_WPRIO      // experiment: issue priority between the two waves of a SIMD (the older one wins by default)
+#define K8_WPRIO 0
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -534,10 +546,21 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   int eb = 0;                 // i % 3
   int young = 0;              // operations that may stay in flight at the next wait
   int prev_ops = 0;           // what the interval before this one issued (D = 3)
-#if K8_STAG
+  // (member, tile) of the tiles a step names -- i-1 (stores), i, i+1 (the chunk to issue) -- are split ONCE per tile and
+  // carried, where a step never looks further ahead than tile i+1 (the float reciprocal + readfirstlanes of split_tile
+  // twice per step sat between the barrier and the step's first MFMA)
+  constexpr bool CARRY = (NC - 1 + D + 1) / NC <= 1;
+  int m_p = 0, t_p = 0, m_c = 0, t_c = 0, m_n = 0, t_n = 0;
+  if constexpr (CARRY) {
+    split_tile(tile_of(0), m_c, t_c);
+    split_tile(tile_of(1), m_n, t_n);
+  }
+#if K8_STAG == 1
   const int sreg0 = NU - 4 + (wave & 3), sreg1 = NU - 4 + ((wave + 2) & 3);      // SKEW: store regions by wave (variant build)
+#elif K8_STAG == 2
+  const int sreg0 = NU - 4 + (wave >> 2), sreg1 = NU - 2 + (wave >> 2);          // the two waves of a SIMD (w, w + 4) never store together
 #else
-  constexpr int sreg0 = CT == 1 ? NU - 2 : NU - 3, sreg1 = NU - 1;               // SKEW: the step's store regions
+  constexpr int sreg0 = CT == 1 ? (K8_SREG0 + K8_SREG1) / 2 : K8_SREG0, sreg1 = K8_SREG1;      // SKEW: the step's store regions
 #endif
   int rd0 = 0, rd1 = 2, rd2 = 2, rd3 = 2;   // SKEW: ring slot row tile t READS in this step = (s - t) mod (t + 2); it writes the slot before
   for (int i = 0; i < ntl; ++i) {
@@ -548,7 +571,12 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       constexpr int a2 = c + D + 1, c2 = a2 % NC;
       const int i2 = i + a2 / NC, e2 = (eb + a2 / NC) % 3;
       int m2, t2;
-      split_tile(tile_of(i2), m2, t2);
+      if constexpr (CARRY) {                              // (member, tile) of tiles i-1, i, i+1 ride in scalar registers
+        m2 = a2 / NC == 0 ? m_c : m_n;
+        t2 = a2 / NC == 0 ? t_c : t_n;
+      } else {
+        split_tile(tile_of(i2), m2, t2);
+      }
       const int32_t *rp = t_rows + (int64_t)t2 * kUCap + 4 * wave;          // wave-uniform: scalar loads
       const char *xm = uniform_ptr(x + (int64_t)m2 * mstride_x);
       int32_t r[4 * NQ];
@@ -585,17 +613,18 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       constexpr int tfin = (c + 1) & 3;
       float *srow = nullptr;
       bool s_any = false, s_whole = false, s_ok = false;
-      if (SKEW && (c == 3 || i > 0)) {
-        int ms, ts;
-        split_tile(tile_of(c == 3 ? i : i - 1), ms, ts);
-        const int r = ts * kRows + tfin * 16 + mi;
-        s_any = true;
-        s_whole = (ts + 1) * kRows <= N;
-        s_ok = r < N;
-        srow = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
-        if (K8_ABL_STORE_LOCAL)       // TIMING ABLATION: every block rewrites its own 64 rows (cache-resident): no HBM writes
-          srow = out + (int64_t)(blockIdx.x * kRows + tfin * 16 + mi) * ldo + (CT * jw * 16 + 4 * mh);
-      }
+      auto store_target = [&]() {                         // (called inside region 2: off the path from the barrier to the first MFMA)
+        if (SKEW && (c == 3 || i > 0)) {
+          const int ms = c == 3 ? m_c : m_p, ts = c == 3 ? t_c : t_p;
+          const int r = ts * kRows + tfin * 16 + mi;
+          s_any = true;
+          s_whole = (ts + 1) * kRows <= N;
+          s_ok = r < N;
+          srow = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
+          if (K8_ABL_STORE_LOCAL)     // TIMING ABLATION: every block rewrites its own 64 rows (cache-resident): no HBM writes
+            srow = out + (int64_t)(blockIdx.x * kRows + tfin * 16 + mi) * ldo + (CT * jw * 16 + 4 * mh);
+        }
+      };
       int late_ops = 0;                                   // SKEW: stores issued behind the step's last DMA (they may stay in flight)
       int aw0 = 0, aw1 = 0;                               // SKEW: where this step's two aggregate passes write (byte offset in A)
       if constexpr (SKEW) {
@@ -605,7 +634,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       }
       if (!SKEW && c == 0 && i > 0) {
         int ms, ts;
-        split_tile(tile_of(i - 1), ms, ts);
+        if constexpr (CARRY) { ms = m_p; ts = t_p; }
+        else split_tile(tile_of(i - 1), ms, ts);
         if ((ts + 1) * kRows <= N) {
           spread_stores = true;
           obase = out + (int64_t)ms * mstride_o + (int64_t)(ts * kRows + tt0 * 16 + mi) * ldo +
@@ -773,11 +803,19 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       // ---- the regions --------------------------------------------------------------------------------------
       gwen_static_for<NU>([&](auto uu) {
         constexpr int u = decltype(uu)::value;
+        if constexpr (K8_WPRIO == 1) {          // the two waves of a SIMD take the issue priority in turns, region by region
+          if (wave < NW / 2) __builtin_amdgcn_s_setprio(u & 1); else __builtin_amdgcn_s_setprio((u & 1) ^ 1);
+        } else if constexpr (K8_WPRIO == 2) {   // the younger wave of a SIMD first in the first half of the step
+          if constexpr (u == 0) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
+          if constexpr (u == NU / 2) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(0); }
+        } else if constexpr (K8_WPRIO == 3) {   // the younger wave of a SIMD first, always
+          if constexpr (u == 0) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
+        }
         // memory instructions of this region
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           constexpr bool late = K8_LATE0 && D == 2 && c == 0 && NQ <= NU;
-          if ((late ? NU - NQ + q : EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
+          if ((late ? NU - NQ + q : SKEW ? q / K8_SKEW_DPR : EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
           if constexpr (DENSE) {
             int32_t row = t2 * kRows + 4 * (NW * q + wave) + mh;
             row = row < N ? row : N - 1;
@@ -798,13 +836,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             ++n_ops;
           }
         }
-        if (!DENSE && u == (SKEW ? 3 : NU - 1) && c2 == 0 && wave < 3) {     // (SKEW: no DMA behind region 3, the late stores are counted)
+        if (!DENSE && u == (SKEW ? (NQ - 1) / K8_SKEW_DPR : NU - 1) && c2 == 0 && wave < 3) {     // (SKEW: with the last DMA: the stores behind are counted)
           const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t2 * (kRows * 32) + wave * 1024
                                      : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
         }
-        if constexpr (SKEW && u >= NU - 4) {
+        if constexpr (SKEW && u == 2) store_target();
+        if constexpr (SKEW && u >= 2) {
           // the stores of the row tile that completed in region 1, BEHIND the step's DMAs (regions 0 .. 3).  A CU takes ~58
           // cycles per store INSTRUCTION whatever its width (tools/experiments/stores/stwave.hip), one at a time, and a
           // wave whose next memory instruction meets stores in the queue stands behind them.  (Dealing the 8 x CT stores
@@ -925,12 +964,15 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       }
     });
     eb = eb + 1 == 3 ? 0 : eb + 1;
+    if constexpr (CARRY) {
+      m_p = m_c; t_p = t_c; m_c = m_n; t_c = t_n;
+      split_tile(tile_of(i + 2), m_n, t_n);
+    }
   }
   if constexpr (SKEW) {
     // ---- drain: row tiles 1 .. 3 of the last tile are 1 .. 3 chunks behind: three more steps of matrix work only (their
     // A slices were written before the last barrier), each completing and storing one row tile ----
-    int ms, ts;
-    split_tile(tile_of(ntl - 1), ms, ts);
+    const int ms = m_p, ts = t_p;                       // (the last tile: shifted once more after the loop)
     const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
     auto store_rt = [&](int rt) {
       const int r = ts * kRows + rt * 16 + mi;
