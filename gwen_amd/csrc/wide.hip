@@ -103,6 +103,9 @@
 #ifndef K8_WPRIO      // experiment: issue priority between the two waves of a SIMD (the older one wins by default)
 #define K8_WPRIO 0
 #endif
+#ifndef K8_EARLYR     // 1: row ids of the next step's chunk loaded behind this step's last DMA (see EARLYR)
+#define K8_EARLYR 1
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -555,6 +558,18 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     split_tile(tile_of(0), m_c, t_c);
     split_tile(tile_of(1), m_n, t_n);
   }
+  // EARLYR: the row ids of the chunk a step issues are loaded (scalar loads) in the step BEFORE, behind its last DMA,
+  // instead of in front of the step's own barrier -- the barrier's fence waits for every outstanding scalar load
+  // (lgkmcnt), i.e. their whole latency stood in front of every barrier
+  constexpr bool EARLYR = K8_EARLYR && CARRY && !DENSE && !ROLES && (NC - 1 + D + 2) / NC <= 1 && NQ < NU;
+  int32_t r[4 * NQ];
+  if constexpr (EARLYR) {
+    const int32_t *rp0 = t_rows + (int64_t)((D + 1) / NC == 0 ? t_c : t_n) * kUCap + 4 * wave;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[4 * q + k] = rp0[4 * NW * q + k];
+  }
 #if K8_STAG == 1
   const int sreg0 = NU - 4 + (wave & 3), sreg1 = NU - 4 + ((wave + 2) & 3);      // SKEW: store regions by wave (variant build)
 #elif K8_STAG == 2
@@ -579,8 +594,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       }
       const int32_t *rp = t_rows + (int64_t)t2 * kUCap + 4 * wave;          // wave-uniform: scalar loads
       const char *xm = uniform_ptr(x + (int64_t)m2 * mstride_x);
-      int32_t r[4 * NQ];
-      if constexpr (!DENSE) {
+      if constexpr (!DENSE && !EARLYR) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -841,6 +855,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
                                      : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
+        }
+        if constexpr (EARLYR && u == (NQ - 1) / (SKEW ? K8_SKEW_DPR : 1) + 1) {
+          constexpr int an = c + D + 2;                   // the chunk the NEXT step issues, counted from this tile's chunk 0
+          const int32_t *rpn = t_rows + (int64_t)(an / NC == 0 ? t_c : t_n) * kUCap + 4 * wave;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[4 * q + k] = rpn[4 * NW * q + k];
         }
         if constexpr (SKEW && u == 2) store_target();
         if constexpr (SKEW && u >= 2) {
