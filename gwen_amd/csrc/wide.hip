@@ -106,6 +106,15 @@
 #ifndef K8_EARLYR     // 1: row ids of the next step's chunk loaded behind this step's last DMA (see EARLYR)
 #define K8_EARLYR 1
 #endif
+#ifndef K8_EARLYR_U   // the region that issues them (8 regions per step where EARLYR applies; -1: the one behind the last DMA)
+#define K8_EARLYR_U 6     // (measured: 205.5-207 us against 208.8 with region 4, 207.5-208 with region 7)
+#endif
+#ifndef K8_AF_EARLY   // experiment: SKEW reads the first unit's A fragments (and computes the first DMA's address) ahead of the barrier
+#define K8_AF_EARLY 0      // (bit 0: the fragments, bit 1: the address.  Measured: 1 -> 212.8-214.3 us against 210.8-212.4; 3 spills into the loop: 283)
+#endif
+#ifndef K8_SBIAS      // 1: SKEW reads a store's bias fragment one region ahead
+#define K8_SBIAS 1
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -611,6 +620,28 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #if K8_STAMP
       uint64_t ts[5] = {0, 0, 0, 0, 0};
 #endif
+      // SKEW: the step's first unit belongs to row tile (c + 1) % 4; unless that is row tile 0 its A slice was written two
+      // or more steps ago, so its fragments are read AHEAD of the barrier (their LDS round trip otherwise stands between
+      // the barrier and the first MFMA); the first DMA's address is computed ahead of it as well
+      constexpr bool AF_EARLY = (K8_AF_EARLY & 1) && SKEW && ((c + 1) & 3) != 0;
+      bf16x8 afrag[NS];                                   // A fragments (NS images) of the unit about to run
+      if constexpr (AF_EARLY) {
+        __builtin_amdgcn_sched_barrier(0);                // (not hoisted into the step before: its registers are full)
+        constexpr int t1 = (c + 1) & 3;
+        const char *ap = lds + kOffA + ring_base(t1) + (t1 == 1 ? rd1 : t1 == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
+      }
+      uint32_t voff_q0 = 0;
+      constexpr bool VOFF_EARLY = (K8_AF_EARLY & 2) && EARLYR && SKEW;
+      if constexpr (VOFF_EARLY) {
+        int32_t row = r[0];
+        row = mh == 1 ? r[1] : row;
+        row = mh == 2 ? r[2] : row;
+        row = mh == 3 ? r[3] : row;
+        voff_q0 = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
+        asm volatile("" : "+v"(voff_q0));
+      }
       K8_TS(0);
       wait_vmcnt(young);
       K8_TS(1);
@@ -639,6 +670,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             srow = out + (int64_t)(blockIdx.x * kRows + tfin * 16 + mi) * ldo + (CT * jw * 16 + 4 * mh);
         }
       };
+      float4_t sbias[CT];
       int late_ops = 0;                                   // SKEW: stores issued behind the step's last DMA (they may stay in flight)
       int aw0 = 0, aw1 = 0;                               // SKEW: where this step's two aggregate passes write (byte offset in A)
       if constexpr (SKEW) {
@@ -718,8 +750,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         if constexpr (SKEW) return lds + kOffA + ring_base(ti) + (ti == 0 ? rd0 : ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2 + k2 * 64;
         else return abase + (((tt0 + ti * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + k2 * 64;
       };
-      bf16x8 afrag[NS];                                   // A fragments (NS images) of the unit about to run
-      {
+      if constexpr (!AF_EARLY) {
         const char *ap = a_src(SKEW ? ((c + 1) & 3) : 0, 0);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
@@ -845,7 +876,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             row = mh == 1 ? r1 : row;
             row = mh == 2 ? r2 : row;
             row = mh == 3 ? r3 : row;
-            const uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
+            uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
+            if (VOFF_EARLY && q == 0) voff = voff_q0;
             glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
             ++n_ops;
           }
@@ -856,7 +888,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
         }
-        if constexpr (EARLYR && u == (NQ - 1) / (SKEW ? K8_SKEW_DPR : 1) + 1) {
+        if constexpr (EARLYR && u == (K8_EARLYR_U >= 0 ? K8_EARLYR_U : (NQ - 1) / (SKEW ? K8_SKEW_DPR : 1) + 1)) {
           constexpr int an = c + D + 2;                   // the chunk the NEXT step issues, counted from this tile's chunk 0
           const int32_t *rpn = t_rows + (int64_t)(an / NC == 0 ? t_c : t_n) * kUCap + 4 * wave;
 #pragma unroll
@@ -865,6 +897,11 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             for (int k = 0; k < 4; ++k) r[4 * q + k] = rpn[4 * NW * q + k];
         }
         if constexpr (SKEW && u == 2) store_target();
+        if constexpr (SKEW && K8_SBIAS) {                   // a store's bias fragment is read one region ahead of it
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            if ((ct == 0 ? sreg0 : sreg1) - 1 == u) sbias[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+        }
         if constexpr (SKEW && u >= 2) {
           // the stores of the row tile that completed in region 1, BEHIND the step's DMAs (regions 0 .. 3).  A CU takes ~58
           // cycles per store INSTRUCTION whatever its width (tools/experiments/stores/stwave.hip), one at a time, and a
@@ -875,7 +912,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             for (int ct = 0; ct < CT; ++ct) {
               if ((ct == 0 ? sreg0 : sreg1) != u) continue;          // (wave-uniform: a scalar branch)
               float4_t o = float4_t{d[ct][tfin][0], d[ct][tfin][1], d[ct][tfin][2], d[ct][tfin][3]} +
-                           *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+                           (K8_SBIAS ? sbias[ct] : *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
               o = relu4(o, relu, floor_bits);
               if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
               float4_t *dst = reinterpret_cast<float4_t *>(srow + ct * 16);
