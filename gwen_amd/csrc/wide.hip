@@ -31,8 +31,16 @@
 // XCD-aware: the tile list (members x tiles) is cut into 8 contiguous ranges, one per blockIdx % 8, and
 // the blocks of an XCD walk their range interleaved, so the halos of concurrently staged tiles meet in
 // that XCD's L2.
-// Numerics: identical to K4's 3xbf16 path term for term (same aggregation order, same split, same MFMA
-// sequence) -- tests compare the two bitwise.
+// Round 3 (256 channels, bf16x3, unions <= 128 rows; DESIGN.md section 4 carries the measurements):
+//   SHIFT  -- the vector work of an aggregate stage runs one region behind the stage's LDS reads (two row buffers);
+//   SKEW   -- row tile t of a tile runs t steps behind row tile 0 (its A slices wait in a ring), the step's units start
+//             with the row tile on its last chunk, and that ONE row tile is stored per step behind the step's DMAs:
+//             a CU takes ~58 cycles per store instruction and its memory pipe is in order, so 8 stores per wave in one
+//             step stood ~3 500 cycles in front of that step's DMAs;
+//   CARRY / EARLYR -- (member, tile) pairs split once per tile and carried in scalar registers; the row ids of the next
+//             step's chunk loaded behind this step's last DMA instead of in front of the barrier's fence.
+// Numerics: identical to K4's split path term for term (same aggregation order, same split, same MFMA
+// sequence per output element) -- tests compare the two bitwise.
 #include "common.h"
 #include "split.h"
 #include <type_traits>
