@@ -123,6 +123,9 @@
 #ifndef K8_SBIAS      // 1: SKEW reads a store's bias fragment one region ahead
 #define K8_SBIAS 1
 #endif
+#ifndef K8_PREF_ROWS  // rows x members from which the planner takes K8 at 64 channels (below: K4; re-measured in round 3, see there)
+#define K8_PREF_ROWS 300000
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -1152,7 +1155,7 @@ extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int c
 
 extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
   if (!gwen_gcn_wide_supported(Fin, Fout) || N <= 0 || members <= 0) return 0;
-  return Fin >= 128 || N * members >= 300000 ? 1 : 0;
+  return Fin >= 128 || N * members >= K8_PREF_ROWS ? 1 : 0;
 }
 
 extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_lid,

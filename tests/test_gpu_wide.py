@@ -133,6 +133,27 @@ def test_wide_members_axis_and_few_tiles(ga, cref):
         assert rel_err(got[members - 1], ref) <= 2e-5
 
 
+@pytest.mark.parametrize("fout", [128, 256])
+@pytest.mark.parametrize("nu,members", [(20, 3), (40, 3), (40, 7)])
+def test_wide_256_skewed_row_tiles_all_members_bitwise(ga, nu, members, fout):
+    """256 input channels with unions <= 128 rows run the SKEWED schedule (row tile t of a tile t steps behind row tile
+    0, one row tile stored per step, three drain steps per block): 1, 2-3 and 6-7 tiles per block, block ranges that
+    cross member boundaries and the partial last tile of every member -- every member bitwise K4's result."""
+    from gwen_amd import ops
+    m, ei, g = _mesh_graph(ga, nu, "hilbert")
+    n = m.num_nodes
+    assert g.tiles()[3] <= 128 and n % 64 != 0
+    x = torch.randn(members, n, 256, generator=torch.Generator().manual_seed(SEED + nu)).to(DEV)
+    w, b = make_params(256, fout)
+    wd, bd = w.to(DEV), b.to(DEV)
+    for relu in (True, False):
+        got = ops.wide_layer(g, x, wd, bd, relu=relu, contract="3xbf16")
+        for k in range(members):
+            assert torch.equal(got[k], ops.layer_fused(g, x[k], wd, bd, relu=relu, exact=False)), (k, relu)
+    again = ops.wide_layer(g, x, wd, bd, relu=False, contract="3xbf16")
+    assert torch.equal(again, got)
+
+
 def test_wide_bipartite(ga):
     """Rectangular graphs (grid -> mesh maps of SURVEY 8(f) f2) tile the same way: x has N_src rows."""
     from gwen_amd import ops
