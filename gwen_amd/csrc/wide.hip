@@ -72,12 +72,6 @@
 #ifndef K8_SHIFT      // 1: the vector work of an aggregate stage runs ONE REGION AFTER the stage's LDS reads (two row
 #define K8_SHIFT 1    // buffers), so the reads' latency sits behind a region of MFMAs instead of in front of the first woven fma
 #endif
-#ifndef K8_AFRAG_FIRST
-#define K8_AFRAG_FIRST 0   // measured: no gain at 256 channels (229-231 vs 226-229 us), the weave loses its shape
-#endif
-#ifndef K8_BFRAG
-#define K8_BFRAG 0         // measured: 64 -> 64 x 16 members 180.6 -> 186.5 us, 256 x 4 within noise (and 4-9 spills)
-#endif
 #ifndef K8_STAMP      // DIAGNOSTIC build (-DK8_STAMP=1, tools/experiments/k8_stamp.py): block K8_STAMP_BLOCK's waves record
 #define K8_STAMP 0    // s_memtime at five points of 32 steps into LDS and dump them to gwen_k8_stamp_buf at the end
 #endif
@@ -90,35 +84,14 @@
 #ifndef K8_ABL_STORE_LOCAL
 #define K8_ABL_STORE_LOCAL 0
 #endif
-#ifndef K8_LATE0      // 1 (with two chunks in flight): the step that stores a tile issues its DMAs in its LAST regions, behind the stores
-#define K8_LATE0 0
-#endif
 #ifndef K8_SKEW       // 1: at 4 chunks per tile, row tile t of a tile runs t steps behind row tile 0 (its A slices wait in a
 #define K8_SKEW 1     // ring), so ONE row tile finishes per step and the output stores are spread over every step
-#endif
-#ifndef K8_STAG       // 1: SKEW's stores dealt over the last four regions by wave instead of regions 5 and 7 for all
-#define K8_STAG 0
-#endif
-#ifndef K8_SREG0      // SKEW: the regions of a step's two stores, and DMAs per region from region 0 on
-#define K8_SREG0 5
-#endif
-#ifndef K8_SREG1
-#define K8_SREG1 7
-#endif
-#ifndef K8_SKEW_DPR
-#define K8_SKEW_DPR 1
-#endif
-#ifndef K8_WPRIO      // experiment: issue priority between the two waves of a SIMD (the older one wins by default)
-#define K8_WPRIO 0
 #endif
 #ifndef K8_EARLYR     // 1: row ids of the next step's chunk loaded behind this step's last DMA (see EARLYR)
 #define K8_EARLYR 1
 #endif
 #ifndef K8_EARLYR_U   // the region that issues them (8 regions per step where EARLYR applies; -1: the one behind the last DMA)
 #define K8_EARLYR_U 6     // (measured: 205.5-207 us against 208.8 with region 4, 207.5-208 with region 7)
-#endif
-#ifndef K8_AF_EARLY   // experiment: SKEW reads the first unit's A fragments (and computes the first DMA's address) ahead of the barrier
-#define K8_AF_EARLY 0      // (bit 0: the fragments, bit 1: the address.  Measured: 1 -> 212.8-214.3 us against 210.8-212.4; 3 spills into the loop: 283)
 #endif
 #ifndef K8_SBIAS      // 1: SKEW reads a store's bias fragment one region ahead
 #define K8_SBIAS 1
@@ -590,13 +563,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[4 * q + k] = rp0[4 * NW * q + k];
   }
-#if K8_STAG == 1
-  const int sreg0 = NU - 4 + (wave & 3), sreg1 = NU - 4 + ((wave + 2) & 3);      // SKEW: store regions by wave (variant build)
-#elif K8_STAG == 2
-  const int sreg0 = NU - 4 + (wave >> 2), sreg1 = NU - 2 + (wave >> 2);          // the two waves of a SIMD (w, w + 4) never store together
-#else
-  constexpr int sreg0 = CT == 1 ? (K8_SREG0 + K8_SREG1) / 2 : K8_SREG0, sreg1 = K8_SREG1;      // SKEW: the step's store regions
-#endif
+  constexpr int sreg0 = CT == 1 ? 6 : 5, sreg1 = 7;       // SKEW: the regions of a step's store(s), behind its DMAs (regions 0 .. 3)
   int rd0 = 0, rd1 = 2, rd2 = 2, rd3 = 2;   // SKEW: ring slot row tile t READS in this step = (s - t) mod (t + 2); it writes the slot before
   for (int i = 0; i < ntl; ++i) {
     gwen_static_for<NC>([&](auto cc) {
@@ -620,39 +587,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
           for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
       }
-      // the bias fragments of this wave's columns, read ahead of the barrier in the step that stores a tile (a read in
-      // front of every store waits a full LDS round trip before the region's MFMAs: 8 of them per tile)
       const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
-      float4_t bfrag[CT];
-      if (c == 0 && K8_BFRAG) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) bfrag[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
-      }
 #if K8_STAMP
       uint64_t ts[5] = {0, 0, 0, 0, 0};
 #endif
-      // SKEW: the step's first unit belongs to row tile (c + 1) % 4; unless that is row tile 0 its A slice was written two
-      // or more steps ago, so its fragments are read AHEAD of the barrier (their LDS round trip otherwise stands between
-      // the barrier and the first MFMA); the first DMA's address is computed ahead of it as well
-      constexpr bool AF_EARLY = (K8_AF_EARLY & 1) && SKEW && ((c + 1) & 3) != 0;
-      bf16x8 afrag[NS];                                   // A fragments (NS images) of the unit about to run
-      if constexpr (AF_EARLY) {
-        __builtin_amdgcn_sched_barrier(0);                // (not hoisted into the step before: its registers are full)
-        constexpr int t1 = (c + 1) & 3;
-        const char *ap = lds + kOffA + ring_base(t1) + (t1 == 1 ? rd1 : t1 == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2;
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
-      }
-      uint32_t voff_q0 = 0;
-      constexpr bool VOFF_EARLY = (K8_AF_EARLY & 2) && EARLYR && SKEW;
-      if constexpr (VOFF_EARLY) {
-        int32_t row = r[0];
-        row = mh == 1 ? r[1] : row;
-        row = mh == 2 ? r[2] : row;
-        row = mh == 3 ? r[3] : row;
-        voff_q0 = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
-        asm volatile("" : "+v"(voff_q0));
-      }
       K8_TS(0);
       wait_vmcnt(young);
       K8_TS(1);
@@ -761,7 +699,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         if constexpr (SKEW) return lds + kOffA + ring_base(ti) + (ti == 0 ? rd0 : ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2 + k2 * 64;
         else return abase + (((tt0 + ti * TSTEP) * 16 + mi) * kPB + 8 * mh) * 2 + k2 * 64;
       };
-      if constexpr (!AF_EARLY) {
+      bf16x8 afrag[NS];                                   // A fragments (NS images) of the unit about to run
+      {
         const char *ap = a_src(SKEW ? ((c + 1) & 3) : 0, 0);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
@@ -798,8 +737,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) {
-                if (!K8_BFRAG) bfrag[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
-                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} + bfrag[ct];
+                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
+                             *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
                 o = relu4(o, relu, floor_bits);
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
@@ -859,19 +798,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       // ---- the regions --------------------------------------------------------------------------------------
       gwen_static_for<NU>([&](auto uu) {
         constexpr int u = decltype(uu)::value;
-        if constexpr (K8_WPRIO == 1) {          // the two waves of a SIMD take the issue priority in turns, region by region
-          if (wave < NW / 2) __builtin_amdgcn_s_setprio(u & 1); else __builtin_amdgcn_s_setprio((u & 1) ^ 1);
-        } else if constexpr (K8_WPRIO == 2) {   // the younger wave of a SIMD first in the first half of the step
-          if constexpr (u == 0) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
-          if constexpr (u == NU / 2) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(0); }
-        } else if constexpr (K8_WPRIO == 3) {   // the younger wave of a SIMD first, always
-          if constexpr (u == 0) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
-        }
         // memory instructions of this region
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          constexpr bool late = K8_LATE0 && D == 2 && c == 0 && NQ <= NU;
-          if ((late ? NU - NQ + q : SKEW ? q / K8_SKEW_DPR : EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
+          if ((EARLY ? (q < NU ? q : NU - 1) : q * NU / NQ) != u) continue;
           if constexpr (DENSE) {
             int32_t row = t2 * kRows + 4 * (NW * q + wave) + mh;
             row = row < N ? row : N - 1;
@@ -887,19 +817,18 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             row = mh == 1 ? r1 : row;
             row = mh == 2 ? r2 : row;
             row = mh == 3 ? r3 : row;
-            uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
-            if (VOFF_EARLY && q == 0) voff = voff_q0;
+            const uint32_t voff = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(c2 * kFC * 4 + mi * 16);
             glds16(xm, voff, lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
             ++n_ops;
           }
         }
-        if (!DENSE && u == (SKEW ? (NQ - 1) / K8_SKEW_DPR : NU - 1) && c2 == 0 && wave < 3) {     // (SKEW: with the last DMA: the stores behind are counted)
+        if (!DENSE && u == (SKEW ? NQ - 1 : NU - 1) && c2 == 0 && wave < 3) {     // (SKEW: with the last DMA: the stores behind are counted)
           const char *src = wave < 2 ? reinterpret_cast<const char *>(t_val) + (int64_t)t2 * (kRows * 32) + wave * 1024
                                      : reinterpret_cast<const char *>(t_lid) + (int64_t)t2 * (kRows * 16);
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
         }
-        if constexpr (EARLYR && u == (K8_EARLYR_U >= 0 ? K8_EARLYR_U : (NQ - 1) / (SKEW ? K8_SKEW_DPR : 1) + 1)) {
+        if constexpr (EARLYR && u == (K8_EARLYR_U >= 0 ? K8_EARLYR_U : NQ)) {
           constexpr int an = c + D + 2;                   // the chunk the NEXT step issues, counted from this tile's chunk 0
           const int32_t *rpn = t_rows + (int64_t)(an / NC == 0 ? t_c : t_n) * kUCap + 4 * wave;
 #pragma unroll
@@ -945,8 +874,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) {
-                if (!K8_BFRAG) bfrag[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
-                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} + bfrag[ct];
+                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
+                             *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
                 o = relu4(o, relu, floor_bits);
                 if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
@@ -996,9 +925,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           const int rl = k * NU / NSTAGE, rv = SHIFT ? (rl + 1 < NU ? rl + 1 : NU - 1) : rl;
           if (rv == u) stage_valu(k);
         }
-        // the next unit's A fragments are requested FIRST (left to itself hipcc sinks the reads behind the region's
-        // fifth MFMA, and the next region's first MFMA then waits for them: an LDS round trip in front of every region)
-        if constexpr (u + 1 < NU && K8_AFRAG_FIRST) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
 #pragma unroll
         for (int k = 0; k < CT * (NS == 2 ? 3 : 6); ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
