@@ -265,7 +265,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   // (in-kernel stamps), and a build that stored nothing ran 167 us against 234 (256 -> 256 x 4 members): a CU drains
   // stores at ~32 GB/s and the in-order waves stand behind them.  The aggregate of a chunk is kept per ROW TILE in a
   // ring of t + 2 slices (written in step s' - 1, read in step s' + t): 14 slices of 5 KiB instead of 2 chunks of 20.
-  constexpr bool SKEW = K8_SKEW && !DENSE && !ROLES && NC == 4 && NTT == 4 && TSTEP == 1 && NS == 2 && D == 1 && KU == 128;
+  // (the dense form -- K3's tall case, two chunks of DMA in flight over 64-slot buffers -- takes the same schedule)
+  constexpr bool SKEW = K8_SKEW && !ROLES && NC == 4 && NTT == 4 && TSTEP == 1 && NS == 2 &&
+                        (DENSE ? (D == 2 && KU == kRows) : (D == 1 && KU == 128));
   constexpr int kSlImg = 16 * kPB * 2, kSl = NS * kSlImg;        // one image / all images of a row tile's slice of a chunk
   constexpr int kImgStride = SKEW ? kSlImg : kAImg;
   constexpr int kOffStage = 0, kOffA = NSTG * kStageBytes, kOffEnt = kOffA + (SKEW ? 14 * kSl : 2 * kABytes);
@@ -399,8 +401,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         bf16x4 im[NS];
         split4n<NS>(a4, im);
         char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
+        if constexpr (SKEW)                               // (the prologue's chunk 0: slot 0 of the row tile's ring)
+          a = lds + kOffA + ring_base(2 * p + (wave >> 2)) + ((lr & 15) * kPB + mi * 4) * 2;
 #pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kAImg) = im[s_];
+        for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kImgStride) = im[s_];
       }
       return;
     }
@@ -955,7 +959,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       prev_ops = n_ops;
       sb = sb + 1 == NSTG ? 0 : sb + 1;
       if constexpr (SKEW) {
-        young = s_whole ? late_ops : 0;                   // (a guarded store may not have issued: wait for everything)
+        // one chunk in flight: only the stores behind the step's last DMA may stay; two: the step's DMAs as well (the
+        // chunk the next wait is for is older than all of them).  A guarded store may not have issued: not counted
+        young = (D == 2 ? n_ops : 0) + (s_whole ? late_ops : 0);
         rd0 = rd0 == 1 ? 0 : rd0 + 1; rd1 = rd1 == 2 ? 0 : rd1 + 1; rd2 = rd2 == 3 ? 0 : rd2 + 1; rd3 = rd3 == 4 ? 0 : rd3 + 1;
       }
     });
