@@ -546,22 +546,23 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   int eb = 0;                 // i % 3
   int young = 0;              // operations that may stay in flight at the next wait
   int prev_ops = 0;           // what the interval before this one issued (D = 3)
-  // (member, tile) of the tiles a step names -- i-1 (stores), i, i+1 (the chunk to issue) -- are split ONCE per tile and
-  // carried, where a step never looks further ahead than tile i+1 (the float reciprocal + readfirstlanes of split_tile
-  // twice per step sat between the barrier and the step's first MFMA)
-  constexpr bool CARRY = (NC - 1 + D + 1) / NC <= 1;
-  int m_p = 0, t_p = 0, m_c = 0, t_c = 0, m_n = 0, t_n = 0;
-  if constexpr (CARRY) {
-    split_tile(tile_of(0), m_c, t_c);
-    split_tile(tile_of(1), m_n, t_n);
-  }
+  // (member, tile) of the tiles a step names -- i-1 (its stores) .. i+HI (the chunk the NEXT step issues) -- are split ONCE per
+  // tile and carried in a window of scalar registers (the float reciprocal + readfirstlanes of split_tile twice per step sat
+  // between the barrier and the step's first MFMA): w[k] = tile i - 1 + k
+  constexpr int HI = (NC + D + 1) / NC, WN = HI + 2;
+  int wm[WN], wt[WN];
+#pragma unroll
+  for (int k = 1; k < WN; ++k) split_tile(tile_of(k - 1), wm[k], wt[k]);
+  wm[0] = wm[1]; wt[0] = wt[1];
   // EARLYR: the row ids of the chunk a step issues are loaded (scalar loads) in the step BEFORE, behind its last DMA,
   // instead of in front of the step's own barrier -- the barrier's fence waits for every outstanding scalar load
   // (lgkmcnt), i.e. their whole latency stood in front of every barrier
-  constexpr bool EARLYR = K8_EARLYR && CARRY && !DENSE && !ROLES && (NC - 1 + D + 2) / NC <= 1 && NQ < NU;
+  constexpr bool EARLYR = K8_EARLYR && !DENSE && !ROLES;
+  constexpr int kLastDma = NQ - 1 < NU - 1 ? NQ - 1 : NU - 1;                   // region of a step's last DMA
+  constexpr int kEarlyU = NU == 8 && K8_EARLYR_U > kLastDma ? K8_EARLYR_U : (kLastDma + 1 < NU ? kLastDma + 1 : NU - 1);
   int32_t r[4 * NQ];
   if constexpr (EARLYR) {
-    const int32_t *rp0 = t_rows + (int64_t)((D + 1) / NC == 0 ? t_c : t_n) * kUCap + 4 * wave;
+    const int32_t *rp0 = t_rows + (int64_t)wt[(D + 1) / NC + 1] * kUCap + 4 * wave;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -577,12 +578,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       constexpr int a2 = c + D + 1, c2 = a2 % NC;
       const int i2 = i + a2 / NC, e2 = (eb + a2 / NC) % 3;
       int m2, t2;
-      if constexpr (CARRY) {                              // (member, tile) of tiles i-1, i, i+1 ride in scalar registers
-        m2 = a2 / NC == 0 ? m_c : m_n;
-        t2 = a2 / NC == 0 ? t_c : t_n;
-      } else {
-        split_tile(tile_of(i2), m2, t2);
-      }
+      m2 = wm[a2 / NC + 1];                               // (the window: tile i + a2 / NC)
+      t2 = wt[a2 / NC + 1];
       const int32_t *rp = t_rows + (int64_t)t2 * kUCap + 4 * wave;          // wave-uniform: scalar loads
       const char *xm = uniform_ptr(x + (int64_t)m2 * mstride_x);
       if constexpr (!DENSE && !EARLYR) {
@@ -613,7 +610,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       bool s_any = false, s_whole = false, s_ok = false;
       auto store_target = [&]() {                         // (called inside region 2: off the path from the barrier to the first MFMA)
         if (SKEW && (c == 3 || i > 0)) {
-          const int ms = c == 3 ? m_c : m_p, ts = c == 3 ? t_c : t_p;
+          const int ms = c == 3 ? wm[1] : wm[0], ts = c == 3 ? wt[1] : wt[0];
           const int r = ts * kRows + tfin * 16 + mi;
           s_any = true;
           s_whole = (ts + 1) * kRows <= N;
@@ -632,9 +629,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         aw1 = (wave >> 2) ? ring_base(3) + w3 * kSl : ring_base(2) + w2 * kSl;
       }
       if (!SKEW && c == 0 && i > 0) {
-        int ms, ts;
-        if constexpr (CARRY) { ms = m_p; ts = t_p; }
-        else split_tile(tile_of(i - 1), ms, ts);
+        const int ms = wm[0], ts = wt[0];
         if ((ts + 1) * kRows <= N) {
           spread_stores = true;
           obase = out + (int64_t)ms * mstride_o + (int64_t)(ts * kRows + tt0 * 16 + mi) * ldo +
@@ -832,9 +827,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
         }
-        if constexpr (EARLYR && u == (K8_EARLYR_U >= 0 ? K8_EARLYR_U : NQ)) {
+        if constexpr (EARLYR && u == kEarlyU) {
           constexpr int an = c + D + 2;                   // the chunk the NEXT step issues, counted from this tile's chunk 0
-          const int32_t *rpn = t_rows + (int64_t)(an / NC == 0 ? t_c : t_n) * kUCap + 4 * wave;
+          const int32_t *rpn = t_rows + (int64_t)wt[an / NC + 1] * kUCap + 4 * wave;
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -966,15 +961,14 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       }
     });
     eb = eb + 1 == 3 ? 0 : eb + 1;
-    if constexpr (CARRY) {
-      m_p = m_c; t_p = t_c; m_c = m_n; t_c = t_n;
-      split_tile(tile_of(i + 2), m_n, t_n);
-    }
+#pragma unroll
+    for (int k = 0; k + 1 < WN; ++k) { wm[k] = wm[k + 1]; wt[k] = wt[k + 1]; }
+    split_tile(tile_of(i + 1 + HI), wm[WN - 1], wt[WN - 1]);
   }
   if constexpr (SKEW) {
     // ---- drain: row tiles 1 .. 3 of the last tile are 1 .. 3 chunks behind: three more steps of matrix work only (their
     // A slices were written before the last barrier), each completing and storing one row tile ----
-    const int ms = m_p, ts = t_p;                       // (the last tile: shifted once more after the loop)
+    const int ms = wm[0], ts = wt[0];                   // (the last tile: shifted once more after the loop)
     const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
     auto store_rt = [&](int rt) {
       const int r = ts * kRows + rt * 16 + mi;
