@@ -99,6 +99,9 @@
 #ifndef K8_PREF_ROWS  // rows x members from which the planner takes K8 at 64 channels (below: K4; re-measured in round 3, see there)
 #define K8_PREF_ROWS 300000
 #endif
+#ifndef K8_X6_128_NW8   // bf16x6 at 128 input channels: 8 waves of 256 registers instead of 16 of 128, by Fout (bit 0: 64,
+#define K8_X6_128_NW8 4 // bit 1: 128, bit 2: 256).  128 -> 256 on 16 waves spills 9-14 registers: 464 us against 376 (8 members)
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -1133,7 +1136,8 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
     constexpr int NWV = FI >= 256 ? (K8_ABL_NOWLO ? 16 : 8) : 16;                                     \
     if constexpr (FI <= 128 || FO <= 128) {                                                           \
       constexpr int D6 = K8_D6 > 0 ? K8_D6 : (FI == 64 ? 2 : 1);                                      \
-      if (x6) return launch<FI, FO, NWV, D6, 128, true, false, 3>(GWEN_ARGS);                         \
+      constexpr int NW6 = (FI == 128 && ((K8_X6_128_NW8 >> (FO == 64 ? 0 : FO == 128 ? 1 : 2)) & 1)) ? 8 : NWV;   \
+      if (x6) return launch<FI, FO, NW6, D6, 128, true, false, 3>(GWEN_ARGS);                         \
     }                                                                                                 \
     constexpr int DV = K8_D > 0 ? K8_D : (FI == 64 ? 2 : 1);                                          \
     return small_union ? launch<FI, FO, NWV, DV, 128, true>(GWEN_ARGS)                                \
