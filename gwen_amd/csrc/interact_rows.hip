@@ -494,7 +494,11 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const float4_t v = *reinterpret_cast<const float4_t *>(yown + (4 * k + gs) * C::PY + 4 * ps);
+#if ABL == 5 || ABL == 7
+              asm volatile("" :: "v"(v));
+#else
               if (wrow + 4 * k + gs < n_rows) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v;
+#endif
               asm volatile("" ::: "memory");
             }
           }
@@ -503,7 +507,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
       const char *p2 = reinterpret_cast<const char *>(G2) + ((uint32_t)i2n[rt] * ldb2 + 16u * gs);
 #pragma unroll
       for (int j = 0; j < C::NJ; ++j) {
-        if constexpr (M2 != kNone)
+        if constexpr (M2 != kNone && ABL != 6 && ABL != 7)
           E[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(p2 + 64 * j);
         else
           E[rt * C::NJ + j] = float4_t{0.f, 0.f, 0.f, 0.f};
