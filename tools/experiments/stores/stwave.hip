@@ -7,7 +7,7 @@
 #include <cstdint>
 typedef float float4_t __attribute__((ext_vector_type(4)));
 // MODE 0: dwordx4, all lanes; 1: dwordx4, lanes 0-31; 2: dword, all lanes; 3: dwordx4 streaming (never rewrites a line);
-// 4: dwordx4 with s_waitcnt vmcnt(0) after each (round trip); 5: dwordx2
+// 4: dwordx4 with s_waitcnt vmcnt(0) after each (round trip); 5: dwordx2; 6: dwordx4, the 64 lanes on ONE contiguous KiB
 template <int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void k(float *out, int reps, size_t stream_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -20,6 +20,7 @@ __global__ __launch_bounds__(NW * 64) void k(float *out, int reps, size_t stream
       const int q = (i * NW + wave) & 63;
       const int ct = q & 15, rt = q >> 4;
       float *p = base + (size_t)(rt * 16 + (lane & 15)) * 256 + ct * 16 + (lane >> 4) * 4;
+      if (MODE == 6) p = base + (size_t)q * 256 + lane * 4;
       if (MODE == 3) p += (size_t)t * stream_stride;
       if (MODE == 2) asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v[0]) : "memory");
       else if (MODE == 5) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(__builtin_shufflevector(v, v, 0, 1)) : "memory");
@@ -50,6 +51,8 @@ int main() {
   run<1, 8>("dwordx4, 32 lanes", d, reps);
   run<5, 8>("dwordx2, 64 lanes", d, reps);
   run<2, 8>("dword,   64 lanes", d, reps);
+  run<6, 8>("dwordx4, 64 lanes on one contiguous KiB", d, reps);
+  run<6, 2>("dwordx4, 64 lanes on one contiguous KiB", d, reps);
   run<3, 8>("dwordx4, 64 lanes, streaming (new lines)", d, reps);
   run<3, 16>("dwordx4, 64 lanes, streaming (new lines)", d, reps);
   run<4, 8>("dwordx4 + vmcnt(0) after each (round trip)", d, reps);
