@@ -830,7 +830,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           glds16(uniform_ptr(src), (uint32_t)lane * 16, lds0 + kOffEnt + e2 * kEntBytes + wave * 1024);
           ++n_ops;
         }
-        if constexpr (EARLYR && u == kEarlyU) {
+        // (only when the next step starts on another tile: the chunks of one tile name the same rows, r[] stays)
+        if constexpr (EARLYR && u == kEarlyU && (c + D + 2) % NC == 0) {
           constexpr int an = c + D + 2;                   // the chunk the NEXT step issues, counted from this tile's chunk 0
           const int32_t *rpn = t_rows + (int64_t)wt[an / NC + 1] * kUCap + 4 * wave;
 #pragma unroll
