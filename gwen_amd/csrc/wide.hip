@@ -102,6 +102,9 @@
 #ifndef K8_X6_128_NW8   // bf16x6 at 128 input channels: 8 waves of 256 registers instead of 16 of 128, by Fout (bit 0: 64,
 #define K8_X6_128_NW8 4 // bit 1: 128, bit 2: 256).  128 -> 256 on 16 waves spills 9-14 registers: 464 us against 376 (8 members)
 #endif
+#ifndef K8_VOFFQ      // 1: DMA row offsets computed once per tile (see VOFFQ)
+#define K8_VOFFQ 1
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -564,12 +567,31 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   constexpr int kLastDma = NQ - 1 < NU - 1 ? NQ - 1 : NU - 1;                   // region of a step's last DMA
   constexpr int kEarlyU = NU == 8 && K8_EARLYR_U > kLastDma ? K8_EARLYR_U : (kLastDma + 1 < NU ? kLastDma + 1 : NU - 1);
   int32_t r[4 * NQ];
+  // VOFFQ (4 chunks per tile): this lane's byte offset of its row in each DMA group is computed ONCE per tile (the row
+  // select by lane quarter + multiply: ~5 vector instructions per DMA) and kept; the chunk's 256 bytes go into the scalar
+  // base.  The matrix pipe and the vector ALU of a SIMD do not run side by side (tools/experiments/pipes/overlap.hip:
+  // their times add), so every vector instruction taken out of the step is time
+  constexpr bool VOFFQ = K8_VOFFQ && EARLYR && NC == 4 && NQ == 4;     // (unions <= 128 rows: four DMA groups per wave)
+  u32x4 voffq = {0, 0, 0, 0};                          // (a vector, not an array: hipcc put the array in scratch)
+  auto make_voffq = [&]() {
+    gwen_static_for<(VOFFQ ? 4 : 0)>([&](auto qq) {
+      constexpr int q = decltype(qq)::value;
+      int32_t r0 = r[4 * q], r1 = r[4 * q + 1], r2 = r[4 * q + 2], r3 = r[4 * q + 3];
+      asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));      // in SGPRs: selects (not a lookup in a scratch array)
+      int32_t row = r0;
+      row = mh == 1 ? r1 : row;
+      row = mh == 2 ? r2 : row;
+      row = mh == 3 ? r3 : row;
+      voffq[q] = (uint32_t)row * (uint32_t)(FIN * 4) + (uint32_t)(mi * 16);
+    });
+  };
   if constexpr (EARLYR) {
     const int32_t *rp0 = t_rows + (int64_t)wt[(D + 1) / NC + 1] * kUCap + 4 * wave;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[4 * q + k] = rp0[4 * NW * q + k];
+    if constexpr (VOFFQ) make_voffq();
   }
   constexpr int sreg0 = CT == 1 ? 6 : 5, sreg1 = 7;       // SKEW: the regions of a step's store(s), behind its DMAs (regions 0 .. 3)
   int rd0 = 0, rd1 = 2, rd2 = 2, rd3 = 2;   // SKEW: ring slot row tile t READS in this step = (s - t) mod (t + 2); it writes the slot before
@@ -583,6 +605,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       int m2, t2;
       m2 = wm[a2 / NC + 1];                               // (the window: tile i + a2 / NC)
       t2 = wt[a2 / NC + 1];
+      if constexpr (VOFFQ && c2 == 0) {                     // a new tile's rows (loaded in the step before)
+        __builtin_amdgcn_sched_barrier(0);                // (hoisted into the step before, the four registers spill there)
+        make_voffq();
+      }
       const int32_t *rp = t_rows + (int64_t)t2 * kUCap + 4 * wave;          // wave-uniform: scalar loads
       const char *xm = uniform_ptr(x + (int64_t)m2 * mstride_x);
       if constexpr (!DENSE && !EARLYR) {
@@ -813,6 +839,13 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             continue;
           }
           int32_t r0 = r[4 * q], r1 = r[4 * q + 1], r2 = r[4 * q + 2], r3 = r[4 * q + 3];
+          if constexpr (VOFFQ) {
+            if (r0 >= 0) {
+              glds16(xm + c2 * kFC * 4, q == 0 ? voffq[0] : q == 1 ? voffq[1] : q == 2 ? voffq[2] : voffq[3], lds0 + kOffStage + sb * kStageBytes + 4 * (NW * q + wave) * (kFC * 4));
+              ++n_ops;
+            }
+            continue;
+          }
           asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));      // in SGPRs: selects, no branches
           if (r0 >= 0) {
             int32_t row = r0;
