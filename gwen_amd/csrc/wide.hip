@@ -105,6 +105,9 @@
 #ifndef K8_VOFFQ      // 1: DMA row offsets computed once per tile (see VOFFQ)
 #define K8_VOFFQ 1
 #endif
+#ifndef K8_PERM       // 1: a gathered row's LDS address by one v_perm_b32 (see PERM)
+#define K8_PERM 1
+#endif
 #ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
 #define K8_NT (-1)
 #endif
@@ -674,6 +677,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       const char *stg = lds + kOffStage + sb1 * kStageBytes + mi * 16;
       u32x4 lid4 = {0, 0, 0, 0};
       float4_t wa = {0.f, 0.f, 0.f, 0.f}, wb = wa, acc = wa;
+      // (the matrix pipe and the vector ALU of a SIMD take turns -- pipes/overlap.hip -- so address arithmetic is step time)
+      constexpr bool PERM = K8_PERM && !DENSE && NSTG == 2 && NC % 2 == 0 && kUCap <= 256 && NW == 8 && KU == 128;   // (elsewhere the extra register spills)
+      const uint32_t lane16b = (uint32_t)(mi * 16);
       // SHIFT: stage k's vector work is issued in the region AFTER its LDS reads (the last stage's in the last region),
       // the two halves of a row's entries landing in two register buffers; without it (one buffer) a region's fma
       // chains wait for the reads issued at its own start: ~150-250 cycles of LDS latency in front of the region's MFMAs
@@ -694,8 +700,16 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const uint32_t pair = lid4[2 * (j - 1) + (u >> 1)];
-            const uint32_t lid = (u & 1) ? (pair >> 16) : (pair & 0xffffu);
-            v[u] = *reinterpret_cast<const float4_t *>(stg + lid * (kFC * 4));
+            if constexpr (PERM) {
+              // the row's byte address in ONE instruction: byte 0 = this lane's 16 mi, byte 1 = the local id (< 256: one
+              // byte of its 16-bit slot), i.e. 256 lid + 16 mi; the stage buffer's base rides in the read's immediate
+              // offset (two buffers, four steps per tile: which one is known per step at compile time)
+              const uint32_t a = __builtin_amdgcn_perm(pair, lane16b, (u & 1) ? 0x0c0c0600u : 0x0c0c0400u);
+              v[u] = *reinterpret_cast<const float4_t *>(lds + (kOffStage + ((c + 1) & 1) * kStageBytes) + a);
+            } else {
+              const uint32_t lid = (u & 1) ? (pair >> 16) : (pair & 0xffffu);
+              v[u] = *reinterpret_cast<const float4_t *>(stg + lid * (kFC * 4));
+            }
           }
         }
       };
