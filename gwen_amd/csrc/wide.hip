@@ -18,7 +18,7 @@
 //   * adds bias / ReLU and stores after the last chunk.
 // One block per CU (16 waves; 8 at Fin = 256, where W alone takes 128 registers per wave) walks its tiles
 // persistently; ONE barrier per 64-feature chunk ("step"):
-//     [scalar loads of the row ids of chunk s+D+1]
+//     [scalar loads of the row ids of chunk s+D+1 -- EARLYR: in the step before]
 //     s_waitcnt vmcnt(n): DMA of chunk s+1 landed;  barrier
 //     2 x (row tiles per wave) regions, each: a share of the step's memory instructions -- the DMAs of chunk
 //     s+D+1 -> stage[s % (D+1)] and the stores of the tile finished in step s-1 --, the LDS reads of a share of
@@ -37,8 +37,11 @@
 //             with the row tile on its last chunk, and that ONE row tile is stored per step behind the step's DMAs:
 //             a CU takes ~58 cycles per store instruction and its memory pipe is in order, so 8 stores per wave in one
 //             step stood ~3 500 cycles in front of that step's DMAs;
-//   CARRY / EARLYR -- (member, tile) pairs split once per tile and carried in scalar registers; the row ids of the next
-//             step's chunk loaded behind this step's last DMA instead of in front of the barrier's fence.
+//   window / EARLYR (every width) -- (member, tile) pairs of tiles i-1 .. i+HI split once per tile and carried in scalar
+//             registers; a tile's row ids loaded once, behind the last DMA of the step before, instead of in front of every
+//             barrier's fence;
+//   VOFFQ / PERM -- vector instructions taken out of the step (the matrix pipe and the vector ALU of a SIMD take turns:
+//             their times add): DMA row offsets once per tile, a gathered row's LDS address by one v_perm_b32.
 // Numerics: identical to K4's split path term for term (same aggregation order, same split, same MFMA
 // sequence per output element) -- tests compare the two bitwise.
 #include "common.h"
