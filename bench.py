@@ -228,9 +228,12 @@ def pmc_traffic(tag_prefixes):
 
 
 def kernel_tags(kind, fin, fout, ns):
-    """Name patterns (prefix, suffix) of the kernel a launcher `kind` ran, as rocprofv3 prints it; ns = bf16 images
-    per operand (2: bf16x3, 3: bf16x6, 0: fp32 MFMA) -- a template argument of every contracting kernel."""
-    return {"wide": [(f"k_wide<{fin}, {fout},", f", {ns}>")], "layer": [(f"k_layer<{fin}, {fout}, {ns},", "")],
+    """Name patterns (prefix, suffix) of the kernel a launcher `kind` ran, as rocprofv3 prints it; ns = images per
+    operand (2: bf16x3, 3: bf16x6, 0: fp32 MFMA, "f16": K8's two scaled fp16 images) -- template arguments of every
+    contracting kernel (k_wide ends in <.., images, f16x3>)."""
+    wide_suffix = ", 2, true>" if ns == "f16" else f", {ns}, false>"
+    ns = 3 if ns == "f16" else ns              # every other kernel runs bf16x6 under the default precision
+    return {"wide": [(f"k_wide<{fin}, {fout},", wide_suffix)], "layer": [(f"k_layer<{fin}, {fout}, {ns},", "")],
             "propagate": ["k_propagate<"], "linear": ["k_linear"],
             "chain": [(f"k_chain<{fin},", f", {ns}>"), "k_gather<"]}[kind]
 
@@ -305,7 +308,8 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30, members=1):
 
 def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's per-GPU load", order="auto"):
     """BASELINE c3's processor stack at c5's per-GPU member count: the regime where HBM bounds the path.
-    ``order``: "auto" = the library's default contraction (bf16x6), "auto_x3" = the bf16x3 split."""
+    ``order``: "auto" = the library's default precision (fp32-class: K8's f16x3 from 128 channels, bf16x6 at 64),
+    "auto_x6" = bf16x6 in every kernel, "auto_x3" = the bf16x3 split."""
     n, e = mesh.num_nodes, mesh.num_edges
     f, m, nl = f or args.hbm_channels, m or args.hbm_members, args.hbm_layers
     torch.manual_seed(23)
@@ -333,7 +337,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
     avg = tot / cnt
     comp = compulsory_bytes(kind, n, e, fin, fout, m)
     ws_mib = 2 * 4 * m * n * f / 2 ** 20
-    ns = 3 if order == "auto" else 2
+    ns = {"auto": "f16" if (kind == "wide" and fin >= 128) else 3, "auto_x6": 3, "auto_x3": 2}[order]
     tags = kernel_tags(kind, fin, fout, ns)
     launches_per_layer = 1
     if kind == "wide" and (fin, fout, ns) == (256, 256, 3):      # bf16x6 at 256 -> 256 = two 256 -> 128 launches
@@ -344,7 +348,13 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
         "workload": f"{what}: {nl} chained GCN layers {f}->{f} + ReLU, {m} members, "
                     f"nu={args.nu} N={n} E={e}; {ws_mib:.0f} MiB in+out per layer (Infinity Cache: 256 MiB)",
         "members": m, "channels": f, "layers": nl, "steps": steps,
-        "contraction": "bf16x6 (library default, fp32-class)" if order == "auto" else "bf16x3 (precision \"3xbf16\")",
+        "contraction": {"f16": "f16x3: two power-of-two-scaled fp16 images per operand, three MFMA terms -- fp32-class, "
+                               "the library default from 128 input channels, ONE launch per layer",
+                        3: "bf16x6: three bf16 images per operand, six MFMA terms -- fp32-class"
+                           + (" (the library default at 64 channels)" if order == "auto" else " (precision \"bf16x6\")")
+                           + ("; 256 -> 256 as two 256 -> 128 launches" if launches_per_layer == 2 else ""),
+                        2: "bf16x3 (precision \"3xbf16\"): two bf16 images, three MFMA terms, ~17 bits per product"}[ns],
+        "launches_per_layer": launches_per_layer,
         "ms_per_step": round(dt * 1e3, 4),
         "edges_per_s": round(m * nl * e / dt),
         "roofline": {"bound": "hbm", "kernel": f"{kind}_f32[{fin}->{fout}] x {m} members",
@@ -694,7 +704,7 @@ def main():
     b_comp = compulsory_bytes(kind, n, e, fin, fout, m_local)
     avg_s = total_s / launches
     achieved = b_l2 / avg_s / 1e9
-    tag = kernel_tags(kind, fin, fout, {"auto": 3, "unfused": 3, "bf16x3": 2, "fused_exact": 0}[args.order])
+    tag = kernel_tags(kind, fin, fout, {"auto": 3, "unfused": 0, "bf16x3": 2, "fused_exact": 0}[args.order])
     default_c2 = (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1)
     per_layer_us = {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())}
     roofline = {
@@ -728,12 +738,13 @@ def main():
                                f"{'/'.join(str(min(a, b)) for a, b in widths)} gathered), {m_local} member/GPU",
                    "nodes": n, "edges": e, "channels": c, "hidden": h, "layers": layers,
                    "members": members, "node_order": args.reorder, "kernel_order": args.order,
-                   "contraction": {"auto": "bf16x6 split: three bf16 images per operand, six MFMA terms, fp32 "
-                                           "accumulation -- fp32-class (see gpu_vs_oracle_rel_err; siblings: "
-                                           "bf16x3, exact_f32)",
+                   "contraction": {"auto": "the library default, fp32-class on each kernel's own split -- at this "
+                                           "model's widths (<= 64) bf16x6: three bf16 images per operand, six MFMA "
+                                           "terms, fp32 accumulation (see gpu_vs_oracle_rel_err; siblings: bf16x3, "
+                                           "exact_f32; from 128 channels K8 runs f16x3: hbm_leg)",
                                    "bf16x3": "bf16x3 split: two bf16 images per operand, three MFMA terms",
                                    "fused_exact": "fp32-input MFMA (exact fp32 products)",
-                                   "unfused": "bf16x6 split in K3"}[args.order],
+                                   "unfused": "fp32-input MFMA in K3 (explicit orders contract in fp32)"}[args.order],
                    "hip_graph": bool(args.graph), "rehearsal": "gloo, all ranks on GPU 0" if args.rehearse_gloo else None,
                    "parallelism": f"ensemble members sharded 1 rank = {m_local} member(s); one all-gather at end"},
         "members_per_s": members * args.steps / elapsed,
@@ -768,17 +779,19 @@ def main():
 
     # ---- HBM-bound leg ----------------------------------------------------------------------------------
     if single and not args.no_hbm_leg:
-        # 256 channels: K8 holds W's images in registers, which three images (bf16x6) exceed -- under the default
-        # precision this width runs on K4; the tile-staged kernel is the bf16x3 tier.  Both are measured.
-        line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x3")
-        line["hbm_leg"]["default_precision_bf16x6"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto")
-        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache: K8 on both splits
-        # (same convention: the leg itself on precision "3xbf16", the library default nested beside it)
+        # 256 channels, the LIBRARY DEFAULT (fp32-class): K8 on the scaled fp16 split, one launch per layer.  Beside it
+        # the faster 17-bit tier (precision "3xbf16") and what the default was before f16x3 (bf16x6: W's three images
+        # for 256 output columns exceed the registers, so two 256 -> 128 launches per layer)
+        line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto")
+        line["hbm_leg"]["tier_3xbf16"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x3")
+        line["hbm_leg"]["precision_bf16x6_two_launches"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x6")
+        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache (default there:
+        # bf16x6 on K8's two-chunk pipeline), the 3xbf16 tier beside it
         line["hbm_leg_64ch"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
-                                       what="c2's width beyond the Infinity Cache", order="auto_x3")
-        line["hbm_leg_64ch"]["default_precision_bf16x6"] = hbm_leg(
+                                       what="c2's width beyond the Infinity Cache", order="auto")
+        line["hbm_leg_64ch"]["tier_3xbf16"] = hbm_leg(
             gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
-            what="c2's width beyond the Infinity Cache", order="auto")
+            what="c2's width beyond the Infinity Cache", order="auto_x3")
 
     # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline

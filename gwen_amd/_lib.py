@@ -45,8 +45,22 @@ class GraphDesc(C.Structure):
 
 
 ORDER_AUTO, ORDER_TRANSFORM_FIRST, ORDER_AGGREGATE_FIRST, ORDER_FUSED, ORDER_FUSED_EXACT = -1, 0, 1, 2, 3
-CONTRACT_BF16X3, CONTRACT_F32, CONTRACT_BF16X6 = 0, 1, 2          # GWEN_CONTRACT_* (include/gwen_hip.h)
-CONTRACT_NAMES = {"3xbf16": CONTRACT_BF16X3, "bf16x3": CONTRACT_BF16X3, "fp32": CONTRACT_F32, "bf16x6": CONTRACT_BF16X6}
+CONTRACT_BF16X3, CONTRACT_F32, CONTRACT_BF16X6, CONTRACT_F16X3 = 0, 1, 2, 3          # GWEN_CONTRACT_* (include/gwen_hip.h)
+CONTRACT_NAMES = {"3xbf16": CONTRACT_BF16X3, "bf16x3": CONTRACT_BF16X3, "fp32": CONTRACT_F32, "bf16x6": CONTRACT_BF16X6,
+                  "f16x3": CONTRACT_F16X3}
+
+
+def dense_contract(code: int) -> int:
+    """"f16x3" on a layer means fp32-class on the kernel's own split: K8 has the scaled fp16 split (from 128 input
+    channels), every other kernel -- K3, K4, K5, K7 -- runs bf16x6 (csrc/forward.hip ``dense_contract``)."""
+    return CONTRACT_BF16X6 if code == CONTRACT_F16X3 else code
+
+
+def wide_contract(fin: int, fout: int, code: int) -> int:
+    """What K8 runs for a layer contract (csrc/forward.hip ``wide_contract``): f16x3 where it has it, else bf16x6."""
+    if code == CONTRACT_F16X3 and not lib().gwen_gcn_wide_contract_supported(fin, fout, code):
+        return CONTRACT_BF16X6
+    return code
 KIND_PROPAGATE, KIND_LINEAR, KIND_LAYER, KIND_CHAIN, KIND_SMALL, KIND_WIDE = 2, 3, 4, 5, 6, 8
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 EW_MUL, EW_ADD = 0, 1

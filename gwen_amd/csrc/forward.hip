@@ -22,11 +22,17 @@ inline int resolve_order(const gwen_layer_desc &L) {
   return L.order;
 }
 
-// contraction of a layer's dense part: AUTO / FUSED layers carry it (bf16x3 or bf16x6), explicit orders are fp32
+// contraction of a layer's dense part: AUTO / FUSED layers carry it (bf16x3, bf16x6 or f16x3), explicit orders are fp32
 inline int contract_of(const gwen_layer_desc &L) {
   if (L.order == GWEN_ORDER_AUTO || L.order == GWEN_ORDER_FUSED)
-    return L.contract == GWEN_CONTRACT_BF16X6 ? GWEN_CONTRACT_BF16X6 : GWEN_CONTRACT_BF16X3;
+    return L.contract == GWEN_CONTRACT_BF16X6 || L.contract == GWEN_CONTRACT_F16X3 ? L.contract : GWEN_CONTRACT_BF16X3;
   return GWEN_CONTRACT_F32;
+}
+// GWEN_CONTRACT_F16X3 on a layer = "fp32-class, the kernel's own split": K8 has the scaled fp16 split from 128 input
+// channels; every other kernel (K3, K4, K5, K7, and K8 at 64 channels) runs its fp32-class split, bf16x6
+inline int dense_contract(int c) { return c == GWEN_CONTRACT_F16X3 ? GWEN_CONTRACT_BF16X6 : c; }
+inline int wide_contract(int c, int64_t fi, int64_t fo) {
+  return c == GWEN_CONTRACT_F16X3 && !gwen_gcn_wide_contract_supported(fi, fo, c) ? GWEN_CONTRACT_BF16X6 : c;
 }
 
 inline int64_t round4(int64_t v) { return (v + 3) / 4 * 4; }
@@ -36,7 +42,8 @@ int make_plan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_t
   for (int32_t i = 0; i < n; ++i) {
     const gwen_layer_desc &L = layers[i];
     if (L.fin < 0 || L.fout < 0) return GWEN_EINVAL;
-    if (L.contract != GWEN_CONTRACT_BF16X3 && L.contract != GWEN_CONTRACT_BF16X6) return GWEN_EINVAL;
+    if (L.contract != GWEN_CONTRACT_BF16X3 && L.contract != GWEN_CONTRACT_BF16X6 && L.contract != GWEN_CONTRACT_F16X3)
+      return GWEN_EINVAL;
     if (i > 0 && layers[i - 1].fout != L.fin) return GWEN_EINVAL;
     const int o = resolve_order(L);
     if ((o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) &&
@@ -116,7 +123,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
   // AUTO layer whose widths K4 takes and that shrinks: worth gathering at fout, i.e. transform-first
   auto shrinking_auto = [&](int32_t i, int contract) {   // never while training: every layer's output must exist
     return !acts && i < n_layers && layers[i].order == GWEN_ORDER_AUTO && layers[i].fout < layers[i].fin &&
-           contract_of(layers[i]) == contract;               // one contraction per chained kernel
+           dense_contract(contract_of(layers[i])) == contract;               // one contraction per chained kernel
   };
   const bool have_grouped = g_col && g_val;          // g_rowptr NULL = uniform layout
 
@@ -125,15 +132,15 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
   bool small = dense != nullptr;
   for (int32_t i = 0; i < n_layers && small; ++i)
     small = layers[i].order == GWEN_ORDER_AUTO &&
-            gwen_gcn_small_supported(N, layers[i].fin, layers[i].fout, contract_of(layers[i]));
+            gwen_gcn_small_supported(N, layers[i].fin, layers[i].fout, dense_contract(contract_of(layers[i])));
   if (small) {
     for (int32_t i = 0; i < n_layers; ++i) {
       const gwen_layer_desc &L = layers[i];
       float *dst = acts ? acts[i] : (i + 1 == n_layers ? out : buf[i & 1]);
       GWEN_TRY(before(GWEN_KIND_SMALL, i, L.fin, L.fout));
       GWEN_TRY(gwen_gcn_small_layer_f32(dense, cur, L.W, L.packed, L.bias, dst, N, L.fin, L.fout, members,
-                                        N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats, contract_of(L),
-                                        stream));
+                                        N * L.fin, N * L.fout, L.relu, lin_ws, P.lin_floats,
+                                        dense_contract(contract_of(L)), stream));
       GWEN_TRY(after());
       cur = dst;
     }
@@ -148,7 +155,7 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
     const int64_t fi = L.fin, fo = L.fout;
     if (projected) {
       // layer i: propagate at width fo with its bias/ReLU; chain layer i+1's projection if it shrinks
-      const int cn = last ? 0 : contract_of(layers[i + 1]);
+      const int cn = last ? 0 : dense_contract(contract_of(layers[i + 1]));
       const bool chain = !last && have_grouped && shrinking_auto(i + 1, cn) &&
                          gwen_gcn_chain_supported(fo, layers[i + 1].fout, 0, 1, cn);
       float *dst = acts ? acts[i] : ((last) ? out : buf[nbuf++ & 1]);
@@ -177,18 +184,19 @@ extern "C" int gwen_gnn_forward_f32(const gwen_graph *graph, const gwen_layer_de
       continue;
     }
     const int o = resolve_order(L);
-    const int cc = contract_of(L);
+    const int cw = wide_contract(contract_of(L), fi, fo);     // K8's
+    const int cc = dense_contract(contract_of(L));             // every other kernel's
     if (o == GWEN_ORDER_FUSED || o == GWEN_ORDER_FUSED_EXACT) {
       const bool chain = have_grouped && L.order == GWEN_ORDER_AUTO && !last && shrinking_auto(i + 1, cc) &&
                          gwen_gcn_chain_supported(fi, fo, layers[i + 1].fout, 0, cc);
       if (!chain && L.order == GWEN_ORDER_AUTO && have_tiles &&
-          gwen_gcn_wide_preferred(N, members, fi, fo) && gwen_gcn_wide_contract_supported(fi, fo, cc) &&
-          (cc == GWEN_CONTRACT_BF16X3 || graph->union_max <= 128)) {   // K8: K4's arithmetic, tile-staged
+          gwen_gcn_wide_preferred(N, members, fi, fo) && gwen_gcn_wide_contract_supported(fi, fo, cw) &&
+          (cw != GWEN_CONTRACT_BF16X6 || graph->union_max <= 128)) {   // K8: the layer tile-staged
         float *dst = acts ? acts[i] : (last ? out : buf[nbuf++ & 1]);
         GWEN_TRY(before(GWEN_KIND_WIDE, i, fi, fo));
         GWEN_TRY(gwen_gcn_wide_layer_f32(graph->t_rows, graph->t_lid, graph->t_val, cur, L.W, L.bias, dst,
                                          N, N, fi, fo, fo, members, N * fi, N * fo, L.relu,
-                                         graph->union_max, cc, stream));
+                                         graph->union_max, cw, stream));
         GWEN_TRY(after());
         cur = dst;
         continue;

@@ -248,7 +248,12 @@ __device__ inline void wait_vmcnt(int n) {
 // DENSE: no graph -- the "union" of a tile is its own 64 rows and the aggregate is the row itself: the kernel is
 // then K3's 3xbf16 projection out = act(x W^T + b) for tall inputs (gwen_gcn_linear_f32 sends them here), with
 // x rows at pitch ldx.
-template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE, int NS>
+// F16: the fp32-class contraction on two SCALED fp16 images per operand (split.h "f16x3"): NS = 2's registers, LDS and MFMA
+// count.  The aggregator scales every (row, 64-feature chunk) by a power of two before cutting it and leaves the exponent
+// and the step from the row's previous chunk in the 32 pad bytes of the row's first image ({e, delta} at byte 128); the
+// matrix side multiplies a row tile's accumulators by 2^delta before the first MFMA of a chunk (lane = destination row in
+// the D layout, so the factor is per lane) and the epilogue un-scales by the row's last exponent and the column's.
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE, int NS, bool F16>
 __global__ __launch_bounds__(NW * 64) void k_wide(
     const int32_t *__restrict__ t_rows, const uint16_t *__restrict__ t_lid,
     const float *__restrict__ t_val, const float *__restrict__ x, const float *__restrict__ W,
@@ -283,8 +288,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   constexpr int kSlImg = 16 * kPB * 2, kSl = NS * kSlImg;        // one image / all images of a row tile's slice of a chunk
   constexpr int kImgStride = SKEW ? kSlImg : kAImg;
   constexpr int kOffStage = 0, kOffA = NSTG * kStageBytes, kOffEnt = kOffA + (SKEW ? 14 * kSl : 2 * kABytes);
-  constexpr int kOffBias = kOffEnt + 3 * kEntBytes, kLds = kOffBias + 1024;
-  static_assert(SKEW || kLds == lds_bytes(NSTG, KU, NS), "LDS layout");
+  constexpr int kOffBias = kOffEnt + 3 * kEntBytes, kOffCs = kOffBias + 1024, kLds = kOffCs + (F16 ? 1024 : 0);
+  static_assert(SKEW || kLds == lds_bytes(NSTG, KU, NS) + (F16 ? 1024 : 0), "LDS layout");
+  static_assert(!F16 || (NS == 2 && !DENSE && !ROLES && kPB * 2 >= kFC * 2 + 8), "f16x3: two images, graph form, pad bytes for {e, delta}");
+  constexpr int kSide = kFC * 2;                        // F16: byte offset of a row's {e, delta} in its first image's row
   auto ring_base = [](int ti) { return (ti * (ti + 3) / 2) * kSl; };     // rings of 2, 3, 4, 5 slices: first slice 0, 2, 5, 9
   static_assert(kLds <= 160 * 1024, "the block's LDS exceeds a CU's");
   constexpr int kStampBytes = K8_STAMP && kLds + NW * 1024 <= 160 * 1024 ? NW * 1024 : 0;   // (diagnostic build, where it fits)
@@ -330,13 +337,35 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   for (int ct = 0; ct < CT; ++ct) {
     const int j = CT * jw + ct;                                // adjacent tiles: full 128-B lines per row
     const float *wrow = W + (int64_t)(j * 16 + mi) * FIN;
+    int kw = 0;                                                // F16: this output column's scale is 2^kw
+    if constexpr (F16) {
+      // the column's largest |w| (its Fin values sit in the four lanes mi, mi + 16, mi + 32, mi + 48); W is read twice
+      // (cache-hot) rather than kept raw in registers beside its images
+      float m = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float *wp = wrow + 8 * (4 * ks + mh);
+        const float4_t w0 = *reinterpret_cast<const float4_t *>(wp);
+        const float4_t w1 = *reinterpret_cast<const float4_t *>(wp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(w0[e]), __builtin_fabsf(w1[e])));
+      }
+      m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+      int ew = gwen::f16_exp_of(m);
+      ew = ew < gwen::kF16Floor ? gwen::kF16Floor : ew;
+      kw = gwen::kF16Top - ew;
+      // the epilogue's column factor 2^-kw (a normal number: ew >= 20)
+      if (mh == 0) reinterpret_cast<float *>(lds + kOffCs)[j * 16 + mi] = __builtin_bit_cast(float, (ew - (gwen::kF16Top - 127)) << 23);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const float *wp = wrow + 8 * (4 * ks + mh);
       const float4_t w0 = *reinterpret_cast<const float4_t *>(wp);
       const float4_t w1 = *reinterpret_cast<const float4_t *>(wp + 4);
       const float w8[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-      gwen::split_images<8, NSW>(w8, bw[ct][ks]);
+      if constexpr (F16) gwen::split_f16<8>(w8, kw, bw[ct][ks][0], bw[ct][ks][1]);
+      else gwen::split_images<8, NSW>(w8, bw[ct][ks]);
     }
   }
   {
@@ -349,6 +378,67 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     for (int ks = 0; ks < KS; ++ks)       // every global load above is waited for here, not inside the pipeline
 #pragma unroll
       for (int s_ = 0; s_ < NSW; ++s_) asm volatile("" : "+v"(bw[ct][ks][s_]));
+
+  // ---- F16: scale + cut of an aggregated row piece; the epilogue's un-scale -----------------------------------
+  // eprev[p]: the biased exponent this lane's row of aggregate pass p was scaled by in the chunk before (a lane
+  // aggregates the same rows of every chunk of a tile)
+  int eprev[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) eprev[p] = gwen::kF16Floor;
+  // the images of this lane's 4 features of a row chunk -> `a` (first image; the others `stride` bytes apart).  F16: the
+  // row chunk's largest |value| (16 lanes of a DPP row hold its 64 features) picks the scale 2^(141 - e); a chunk is never
+  // scaled more than 2^16 finer than the chunk before it (the accumulators grow by at most that factor when they are
+  // re-expressed), `first` = a tile's first chunk (nothing accumulated yet)
+  auto put_images = [&](const float4_t &acc, char *a, int stride, int p, bool first) {
+    if constexpr (F16) {
+      float m3, m;
+      asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m3) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
+      asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m) : "v"(m3), "v"(acc[3]));
+      int e = gwen::f16_exp_of(m);
+      e = max(e, __builtin_amdgcn_update_dpp(0, e, 0xb1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+      e = max(e, __builtin_amdgcn_update_dpp(0, e, 0x4e, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+      e = max(e, __builtin_amdgcn_update_dpp(0, e, 0x141, 0xf, 0xf, true));      // row_half_mirror
+      e = max(e, __builtin_amdgcn_update_dpp(0, e, 0x140, 0xf, 0xf, true));      // row_mirror: all 16 lanes hold the row's
+      // a fresh scale leaves kF16Guard binades of headroom, and a chunk whose maximum fits under the scale of the chunk
+      // before it -- and is not more than kF16Keep binades below it -- KEEPS that scale (delta = 0): the matrix side then
+      // has nothing to re-express, which it checks per wave (one compare + branch instead of 4 CT multiplications)
+      int ecur = max(e + gwen::kF16Guard, gwen::kF16Floor);
+      int delta = 0;
+      if (!first) {
+        const int ep = eprev[p];
+        const bool keep = e <= ep && e + gwen::kF16Keep >= ep;
+        ecur = keep ? ep : max(ecur, ep - gwen::kF16Back);
+        delta = ep - ecur;
+      }
+      eprev[p] = ecur;
+      const float f4[4] = {acc[0], acc[1], acc[2], acc[3]};
+      bf16x4 h, l;
+      gwen::split_f16<4>(f4, gwen::kF16Top - ecur, h, l);
+      *reinterpret_cast<bf16x4 *>(a) = h;
+      *reinterpret_cast<bf16x4 *>(a + stride) = l;
+      typedef int int2_t __attribute__((ext_vector_type(2)));
+      if (mi == 0) *reinterpret_cast<int2_t *>(a + kSide) = int2_t{ecur, delta};     // (mi == 0: `a` is the row's first byte)
+    } else {
+      bf16x4 im[NS];
+      split4n<NS>(acc, im);
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * stride) = im[s_];
+    }
+  };
+  // accumulators of 4 output columns (from col0) of a destination row -> the layer's output before the ReLU.  F16: the
+  // accumulators are in the scale of the row's last chunk (exponent er) and of the columns (factors in LDS): two exact
+  // multiplications by powers of two, the second fused with the bias add (one rounding, as d + bias)
+  auto finish4 = [&](const f32x4 &dv, int er, int col0, const float4_t &b4) -> float4_t {
+    if constexpr (F16) {
+      const float4_t cs = *reinterpret_cast<const float4_t *>(lds + kOffCs + col0 * 4);
+      float4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(__builtin_ldexpf(dv[e], er - gwen::kF16Top), cs[e], b4[e]);
+      return o;
+    } else {
+      return float4_t{dv[0], dv[1], dv[2], dv[3]} + b4;
+    }
+  };
 
   // ---- pipeline pieces ------------------------------------------------------------------------------------
   // DMA of (tile g, chunk c) into stage[sb]; with c == 0 also the tile's entry weights / local ids into
@@ -454,13 +544,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int lr = 4 * NW * p + 4 * wave + mh;
-      bf16x4 im[NS];
-      split4n<NS>(acc[p], im);
       char *a = lds + kOffA + ab * kABytes + (lr * kPB + mi * 4) * 2;
       if constexpr (SKEW)                               // (the prologue's chunk 0: slot 0 of the row tile's ring)
         a = lds + kOffA + ring_base(2 * p + (wave >> 2)) + ((lr & 15) * kPB + mi * 4) * 2;
-#pragma unroll
-      for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kImgStride) = im[s_];
+      put_images(acc[p], a, kImgStride, p, true);        // (only called for a tile's chunk 0)
     }
   };
 
@@ -501,6 +588,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int i = 0; i < NTT; ++i) d[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int erow[NTT];                 // F16: exponent of the scale row tile i's accumulators are in once its last chunk ran
+#pragma unroll
+  for (int i = 0; i < NTT; ++i) erow[i] = gwen::kF16Top;
 
   // Stores of a finished tile, issued AFTER the step's DMAs so that a later top-of-step wait can leave them
   // in flight.  The waits count instructions, so the count must be exact: a tile whose 64 rows all exist is
@@ -518,8 +608,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int j = CT * jw + ct;
-        float4_t o = float4_t{d[ct][i][0], d[ct][i][1], d[ct][i][2], d[ct][i][3]} +
-                     *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh);
+        float4_t o = finish4(d[ct][i], erow[i], j * 16 + 4 * mh, *reinterpret_cast<const float4_t *>(bl + j * 16 + 4 * mh));
         o = relu4(o, relu, floor_bits);
         float *dst = om + (int64_t)r * ldo + j * 16 + 4 * mh;
         if (whole || r < N) *reinterpret_cast<float4_t *>(dst) = o;
@@ -641,6 +730,12 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       // stored in this step's LATE regions (its next tile starts in the LAST regions of the next step).  Tile i's row tile 0
       // completes in step 3, row tiles 1 .. 3 of tile i - 1 in steps 0 .. 2.
       constexpr int tfin = (c + 1) & 3;
+      const char *abase = lds + kOffA + (s & 1) * kABytes;
+      // F16: {e, delta} of destination row mi in the chunk row tile ti is about to contract (the pad bytes of the row)
+      auto side_src = [&](int ti) -> const char * {
+        if constexpr (SKEW) return lds + kOffA + ring_base(ti) + (ti == 0 ? rd0 : ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + mi * (kPB * 2) + kSide;
+        else return abase + ((tt0 + ti * TSTEP) * 16 + mi) * (kPB * 2) + kSide;
+      };
       float *srow = nullptr;
       bool s_any = false, s_whole = false, s_ok = false;
       auto store_target = [&]() {                         // (called inside region 2: off the path from the barrier to the first MFMA)
@@ -651,6 +746,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           s_whole = (ts + 1) * kRows <= N;
           s_ok = r < N;
           srow = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
+          if constexpr (F16) erow[tfin] = *reinterpret_cast<const int *>(side_src(tfin));   // (its last chunk's slot: read this step)
           if (K8_ABL_STORE_LOCAL)     // TIMING ABLATION: every block rewrites its own 64 rows (cache-resident): no HBM writes
             srow = out + (int64_t)(blockIdx.x * kRows + tfin * 16 + mi) * ldo + (CT * jw * 16 + 4 * mh);
         }
@@ -686,13 +782,31 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       // SHIFT: stage k's vector work is issued in the region AFTER its LDS reads (the last stage's in the last region),
       // the two halves of a row's entries landing in two register buffers; without it (one buffer) a region's fma
       // chains wait for the reads issued at its own start: ~150-250 cycles of LDS latency in front of the region's MFMAs
-      constexpr bool SHIFT = K8_SHIFT && !DENSE && NSTAGE == NU && NU >= 4 && !(NS == 3 && NW == 16);   // (128-register waves: bf16x6 would spill)
+      constexpr bool SHIFT = K8_SHIFT && !DENSE && NSTAGE == NU && NU >= 4 && !(NS == 3 && NW == 16) &&   // (128-register waves: bf16x6 would spill)
+                             !(F16 && FIN == 256 && FOUT == 256);   // (f16x3 at 256 -> 256: the second row buffer does not fit the
+                                                                    //  registers -- 10 spilled, reloaded from scratch in every step: 327 us
+                                                                    //  against 268 without it; three-row buffers and reads issued at the
+                                                                    //  end of the region before measured 277 / 269)
       constexpr int NVB = SHIFT ? 2 : 1;
       float4_t vbuf[NVB][4];
       auto stage_loads = [&](int k) {                   // k = 4 pass + stage
         const int p = k >> 2, j = k & 3;
         const int lr = 4 * NW * p + 4 * wave + mh;
         float4_t (&v)[4] = vbuf[SHIFT && j == 2 ? NVB - 1 : 0];
+        // entry q (0 .. 7) of this lane's row -> dst
+        auto row_load = [&](int q, float4_t &dst) {
+          const uint32_t pair = lid4[q >> 1];
+          if constexpr (PERM) {
+            // the row's byte address in ONE instruction: byte 0 = this lane's 16 mi, byte 1 = the local id (< 256: one
+            // byte of its 16-bit slot), i.e. 256 lid + 16 mi; the stage buffer's base rides in the read's immediate
+            // offset (two buffers, four steps per tile: which one is known per step at compile time)
+            const uint32_t a = __builtin_amdgcn_perm(pair, lane16b, (q & 1) ? 0x0c0c0600u : 0x0c0c0400u);
+            dst = *reinterpret_cast<const float4_t *>(lds + (kOffStage + ((c + 1) & 1) * kStageBytes) + a);
+          } else {
+            const uint32_t lid = (q & 1) ? (pair >> 16) : (pair & 0xffffu);
+            dst = *reinterpret_cast<const float4_t *>(stg + lid * (kFC * 4));
+          }
+        };
         if constexpr (DENSE) {
           if (j == 1) v[0] = *reinterpret_cast<const float4_t *>(stg + lr * (kFC * 4));
         } else if (j == 0) {
@@ -701,19 +815,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           wb = *reinterpret_cast<const float4_t *>(ent + lr * 32 + 16);
         } else if (j == 1 || j == 2) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t pair = lid4[2 * (j - 1) + (u >> 1)];
-            if constexpr (PERM) {
-              // the row's byte address in ONE instruction: byte 0 = this lane's 16 mi, byte 1 = the local id (< 256: one
-              // byte of its 16-bit slot), i.e. 256 lid + 16 mi; the stage buffer's base rides in the read's immediate
-              // offset (two buffers, four steps per tile: which one is known per step at compile time)
-              const uint32_t a = __builtin_amdgcn_perm(pair, lane16b, (u & 1) ? 0x0c0c0600u : 0x0c0c0400u);
-              v[u] = *reinterpret_cast<const float4_t *>(lds + (kOffStage + ((c + 1) & 1) * kStageBytes) + a);
-            } else {
-              const uint32_t lid = (u & 1) ? (pair >> 16) : (pair & 0xffffu);
-              v[u] = *reinterpret_cast<const float4_t *>(stg + lid * (kFC * 4));
-            }
-          }
+          for (int u = 0; u < 4; ++u) row_load(4 * (j - 1) + u, v[u]);
         }
       };
       auto stage_valu = [&](int k) {
@@ -729,16 +831,13 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
           for (int u = 0; u < 4; ++u)
             acc = fma4(w4[u], v[u], acc);
-        } else if (j == 3) {
-          bf16x4 im[NS];
-          split4n<NS>(acc, im);
+        }
+        if (j == 3) {
           char *a = lds + kOffA + ab1 * kABytes + (lr * kPB + mi * 4) * 2;
           if constexpr (SKEW) a = lds + kOffA + (p == 0 ? aw0 : aw1) + ((lr & 15) * kPB + mi * 4) * 2;
-#pragma unroll
-          for (int s_ = 0; s_ < NS; ++s_) *reinterpret_cast<bf16x4 *>(a + s_ * kImgStride) = im[s_];
+          put_images(acc, a, kImgStride, p, (c + 1) % NC == 0);
         }
       };
-      const char *abase = lds + kOffA + (s & 1) * kABytes;
       // first image of the A fragment of unit (row tile ti, k-step k2 of its chunk)
       auto a_src = [&](int ti, int k2) -> const char * {
         if constexpr (SKEW) return lds + kOffA + ring_base(ti) + (ti == 0 ? rd0 : ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + (mi * kPB + 8 * mh) * 2 + k2 * 64;
@@ -749,6 +848,33 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         const char *ap = a_src(SKEW ? ((c + 1) & 3) : 0, 0);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
+      }
+      if constexpr (F16) {
+        // the row tiles that continue a tile in this step (not on their first chunk): accumulators into the new chunk's
+        // scale, x 2^delta (exact).  The aggregator keeps a row's scale whenever it can, so ONE test per wave and step
+        // -- the deltas of the step's row tiles or-ed, read with the first A fragments -- skips this almost always.
+        int dl[NTT], any = 0;
+        gwen_static_for<NTT>([&](auto tt) {
+          constexpr int ti = decltype(tt)::value;
+          constexpr int cu = SKEW ? ((c - ti) & 3) : c;
+          dl[ti] = 0;
+          if constexpr (cu != 0) {
+            dl[ti] = *reinterpret_cast<const int *>(side_src(ti) + 4);
+            any |= dl[ti];
+          }
+        });
+        if (__builtin_amdgcn_ballot_w64(any != 0) != 0) {
+          gwen_static_for<NTT>([&](auto tt) {
+            constexpr int ti = decltype(tt)::value;
+            constexpr int cu = SKEW ? ((c - ti) & 3) : c;
+            if constexpr (cu != 0) {
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[ct][ti][e] = __builtin_ldexpf(d[ct][ti][e], dl[ti]);
+            }
+          });
+        }
       }
       if constexpr (ROLES) {
         // ---- ROLES: every DMA of chunk s+2 first, then the step's two halves -- X = aggregate(s+1) (LDS reads,
@@ -890,7 +1016,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             for (int k = 0; k < 4; ++k) r[4 * q + k] = rpn[4 * NW * q + k];
         }
         if constexpr (SKEW && u == 2) store_target();
-        if constexpr (SKEW && K8_SBIAS) {                   // a store's bias fragment is read one region ahead of it
+        if constexpr (SKEW && K8_SBIAS && !F16) {           // a store's bias fragment is read one region ahead of it
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
             if ((ct == 0 ? sreg0 : sreg1) - 1 == u) sbias[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
@@ -904,8 +1030,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
               if ((ct == 0 ? sreg0 : sreg1) != u) continue;          // (wave-uniform: a scalar branch)
-              float4_t o = float4_t{d[ct][tfin][0], d[ct][tfin][1], d[ct][tfin][2], d[ct][tfin][3]} +
-                           (K8_SBIAS ? sbias[ct] : *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
+              float4_t o = finish4(d[ct][tfin], erow[tfin], (CT * jw + ct) * 16 + 4 * mh,
+                                   K8_SBIAS && !F16 ? sbias[ct] : *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
               o = relu4(o, relu, floor_bits);
               if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
               float4_t *dst = reinterpret_cast<float4_t *>(srow + ct * 16);
@@ -927,8 +1053,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               float *orow = obase + (int64_t)(ti * TSTEP * 16) * ldo;
 #pragma unroll
               for (int ct = 0; ct < CT; ++ct) {
-                float4_t o = float4_t{d[ct][ti][0], d[ct][ti][1], d[ct][ti][2], d[ct][ti][3]} +
-                             *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+                float4_t o = finish4(d[ct][ti], erow[ti], (CT * jw + ct) * 16 + 4 * mh,
+                                     *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
                 o = relu4(o, relu, floor_bits);
                 if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
                 if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
@@ -958,12 +1084,19 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
             for (int s_ = 0; s_ < NS; ++s_) afrag[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
           }
+          if constexpr (F16 && k2 == 0) {
+            // the exponent the finished accumulators are in: SKEW stores the row tile later in this very step and reads it
+            // then (store_target); the other forms store in the next step, when the slot is being rewritten
+            if constexpr (cu == NC - 1 && !SKEW) erow[ti] = *reinterpret_cast<const int *>(side_src(ti));
+          }
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
               // the first unit of a tile starts from a ZERO C operand (an inline constant of the MFMA) instead of
               // re-zeroed accumulator registers: 32 moves per tile and wave less on the vector ALU
               const f32x4 cin = (cu == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
-              if constexpr (K8_ABL_NOWLO) {
+              if constexpr (F16) {
+                d[ct][ti] = gwen::mma_split_f16(bw[ct][ks], acur, cin);
+              } else if constexpr (K8_ABL_NOWLO) {
                 bf16x8 wt[NS];
 #pragma unroll
                 for (int s_ = 0; s_ < NS; ++s_) wt[s_] = bw[ct][ks][0];
@@ -1029,8 +1162,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       float *row = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        float4_t o = float4_t{d[ct][rt][0], d[ct][rt][1], d[ct][rt][2], d[ct][rt][3]} +
-                     *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
+        float4_t o = finish4(d[ct][rt], erow[rt], (CT * jw + ct) * 16 + 4 * mh,
+                             *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
         o = relu4(o, relu, floor_bits);
         if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
         if (r < N) *reinterpret_cast<float4_t *>(row + ct * 16) = o;
@@ -1046,6 +1179,23 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           bf16x8 af[NS];
 #pragma unroll
           for (int s_ = 0; s_ < NS; ++s_) af[s_] = *reinterpret_cast<const bf16x8 *>(ap + s_ * kImgStride);
+          if constexpr (F16) {
+            if (k2 == 0) {                                    // (cu >= 1 in the drain: never a tile's first chunk)
+              typedef int int2_t __attribute__((ext_vector_type(2)));
+              const int2_t sd = *reinterpret_cast<const int2_t *>(
+                  lds + kOffA + ring_base(ti) + (ti == 1 ? rd1 : ti == 2 ? rd2 : rd3) * kSl + mi * (kPB * 2) + kSide);
+              if (__builtin_amdgcn_ballot_w64(sd[1] != 0) != 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) d[ct][ti][e] = __builtin_ldexpf(d[ct][ti][e], sd[1]);
+              }
+              if constexpr (cu == NC - 1) erow[ti] = sd[0];
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split_f16(bw[ct][2 * cu + k2], af, d[ct][ti]);
+            continue;
+          }
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][2 * cu + k2], af, d[ct][ti]);
         }
@@ -1064,7 +1214,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #endif
 }
 
-template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false, int NS = 2>
+template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false, int NS = 2, bool F16 = false>
 int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st, int64_t ldx = FIN) {
@@ -1083,7 +1233,7 @@ int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, con
   // members: 204 -> 191 us per layer in the 4-layer stack); a working set that fits stays on plain stores (the
   // next layer reads its input from the cache: 256 channels x 1 member 69.7 vs 74.3 us with nt)
   const int nt = K8_NT >= 0 ? K8_NT : (members * N * (int64_t)(FIN + FOUT) * 4 > (int64_t(300) << 20) ? 1 : 0);
-  k_wide<FIN, FOUT, NW, D, KU, EARLY, DENSE, NS><<<(unsigned)blocks, NW * 64, 0, st>>>(
+  k_wide<FIN, FOUT, NW, D, KU, EARLY, DENSE, NS, F16><<<(unsigned)blocks, NW * 64, 0, st>>>(
       t_rows, t_lid, t_val, x, W, bias, out, (int32_t)N, (int32_t)T, (int32_t)G, ldo, msx, mso, relu, (int32_t)ldx, nt);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
@@ -1127,6 +1277,7 @@ extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
 extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract) {
   if (!gwen_gcn_wide_supported(Fin, Fout)) return 0;
   if (contract == GWEN_CONTRACT_BF16X3) return 1;
+  if (contract == GWEN_CONTRACT_F16X3) return Fin >= 128 ? 1 : 0;     // (64 channels: bf16x6 has its own two-chunk pipeline)
   // bf16x6 at 256 -> 256: three images of W are 192 of the 256 registers a wave has there (hipcc spills 85-91 of
   // them: 141-157 us per pass on one member against K4's 127, measured); 256 -> 64 / 128 hold half / a quarter of
   // the columns per wave and fit, so 256 -> 256 runs as two 256 -> 128 launches (gwen_gcn_wide_layer_f32).
@@ -1168,6 +1319,21 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
   const bool small_union = union_max <= 128;
   const bool x6 = contract == GWEN_CONTRACT_BF16X6;
   if (x6 && !small_union) return GWEN_ERANGE;
+  if (contract == GWEN_CONTRACT_F16X3) {
+    // fp32-class on two scaled fp16 images: bf16x3's pipeline (SKEW at 256 -> 128 / 256, unions up to 192 rows), ONE launch
+#define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
+#define GWEN_H(FI, FO)                                                                                \
+  if (Fin == FI && Fout == FO) {                                                                      \
+    constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
+    return small_union ? launch<FI, FO, NWV, 1, 128, true, false, 2, true>(GWEN_ARGS)                 \
+                       : launch<FI, FO, NWV, 1, 192, true, false, 2, true>(GWEN_ARGS);                \
+  }
+    GWEN_H(128, 64); GWEN_H(128, 128); GWEN_H(128, 256);
+    GWEN_H(256, 64); GWEN_H(256, 128); GWEN_H(256, 256);
+#undef GWEN_H
+#undef GWEN_ARGS
+    return GWEN_EINVAL;
+  }
   if (x6 && Fin == 256 && Fout == 256) {
     // three images of W for all 256 output columns are 192 registers per wave; for 128 columns they fit.  The layer
     // runs as TWO launches of the 256 -> 128 kernel, each staging and aggregating the rows again and writing its half

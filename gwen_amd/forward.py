@@ -15,10 +15,12 @@ from torch import Tensor
 from . import _lib
 from .graph import GraphCSR, _ptr, _stream
 
-# order string -> (GWEN_ORDER_*, GWEN_CONTRACT_* of an AUTO / FUSED layer).  "auto" / "fused" contract on the
-# fp32-class bf16x6 split (the default precision), "auto_x3" / "fused_x3" on the faster bf16x3 split; the
+# order string -> (GWEN_ORDER_*, GWEN_CONTRACT_* of an AUTO / FUSED layer).  "auto" is the default precision,
+# fp32-class on the kernel's own split ("f16x3": K8 from 128 input channels on two scaled fp16 images, every other
+# kernel on bf16x6); "auto_x6" / "fused" are bf16x6 in every kernel, "auto_x3" / "fused_x3" the faster bf16x3 split; the
 # explicit two-launch orders and "fused_exact" use the fp32-input MFMA whatever the second entry says.
-_ORDERS = {"auto": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X6), "auto_x3": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X3),
+_ORDERS = {"auto": (_lib.ORDER_AUTO, _lib.CONTRACT_F16X3), "auto_x6": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X6),
+           "auto_x3": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X3),
            "transform_first": (_lib.ORDER_TRANSFORM_FIRST, _lib.CONTRACT_BF16X6),
            "aggregate_first": (_lib.ORDER_AGGREGATE_FIRST, _lib.CONTRACT_BF16X6),
            "fused": (_lib.ORDER_FUSED, _lib.CONTRACT_BF16X6), "fused_x3": (_lib.ORDER_FUSED, _lib.CONTRACT_BF16X3),
@@ -141,7 +143,7 @@ class StackForward:
         # per fresh graph -- the reference's loaders hand over a new edge_index per batch)
         self._small = graph.dense() is not None and all(
             d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, d.fin, d.fout,
-                                                                               d.contract)
+                                                                               _lib.dense_contract(d.contract))
             for d in self.desc)
         # long rows beyond K7's graphs: per-layer K3 + segmented K2 (ops.propagate) instead of the C launcher,
         # whose fused kernels walk a row serially
@@ -171,7 +173,7 @@ class StackForward:
         g = self.graph
         want_tiles = (not self._small) and any(
             d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_wide_preferred(g.num_nodes, members, d.fin, d.fout)
-            and _lib.lib().gwen_gcn_wide_contract_supported(d.fin, d.fout, d.contract)
+            and _lib.lib().gwen_gcn_wide_contract_supported(d.fin, d.fout, _lib.wide_contract(d.fin, d.fout, d.contract))
             for d in self.desc)
         key = (members if want_tiles else 0, want_tiles)
         if self._gd_key != key:
@@ -200,7 +202,8 @@ class StackForward:
             g, hit = self.graph, None
             wants = (not self._small) and (not self._long) and g.num_src < 0 and any(
                 d.order == _lib.ORDER_AUTO and _lib.lib().gwen_gcn_wide_preferred(g.num_nodes, members, d.fin, d.fout)
-                and _lib.lib().gwen_gcn_wide_contract_supported(d.fin, d.fout, d.contract) for d in self.desc)
+                and _lib.lib().gwen_gcn_wide_contract_supported(d.fin, d.fout, _lib.wide_contract(d.fin, d.fout, d.contract))
+                for d in self.desc)
             if wants and g.tiles() is None:
                 cl = g.clustered()
                 if cl is not None:

@@ -63,7 +63,7 @@ class GCNConv(nn.Module):
         self.add_self_loops, self.normalize = add_self_loops, normalize
         self._cached_graph: Optional[GraphCSR] = None
         self._packed = None                            # (weight identity/version, K7 image) for inference
-        self.order = "auto"                            # "auto" | "auto_x3" | "transform_first" | "aggregate_first" | ...
+        self.order = "auto"                            # "auto" | "auto_x6" | "auto_x3" | "transform_first" | "aggregate_first" | ...
         if bias:
             self.bias = nn.Parameter(torch.empty(out_channels))
         else:
@@ -79,10 +79,11 @@ class GCNConv(nn.Module):
 
     @property
     def precision(self) -> str:
-        """"bf16x6" (default): contractions on the bf16 matrix cores with both operands cut into three bf16
-        images -- six MFMA terms, fp32 accumulation, 24 bits per operand: fp32-class (<= 2e-6 on the 6-layer
-        model; the reference's `lin` is an fp32 GEMM, models_gnn.py:118-130) at 6/16 of the fp32 MFMA's cost;
-        "3xbf16": the faster two-image split (~17 bits per product, 7e-6 on the model; meets the 1e-4 contract);
+        """"f16x3" (default): fp32-class contractions (<= 2e-6 per layer against fp64; the reference's `lin` is an fp32
+        GEMM, models_gnn.py:118-130) on each kernel's own split -- the tile-staged wide layer K8 cuts both operands into
+        two power-of-two-scaled fp16 images from 128 input channels (three MFMA terms, one launch at 256 -> 256), every
+        other kernel into three bf16 images (six terms); "bf16x6": three bf16 images in every kernel (K8 at 256 -> 256
+        then runs two launches); "3xbf16": the faster two-image split (~17 bits per product, 7e-6 on the model; meets the 1e-4 contract);
         "fp32": the fp32-input MFMA (exact fp32 products, bit-identical to a k-ordered fmaf chain).  The same
         rule holds in training (forward; the backward contracts with "3xbf16") and inference, in the per-layer
         path and in the stack launcher."""
@@ -91,8 +92,10 @@ class GCNConv(nn.Module):
 
     @precision.setter
     def precision(self, value: str) -> None:
-        if value == "bf16x6":
+        if value == "f16x3":
             self.order = "auto"
+        elif value == "bf16x6":
+            self.order = "auto_x6"
         elif value == "3xbf16":
             self.order = "auto_x3"
         elif value == "fp32":
@@ -100,7 +103,7 @@ class GCNConv(nn.Module):
             self.order = "fused_exact" if layer_supported(self.in_channels, self.out_channels) else \
                 ("aggregate_first" if self.in_channels < self.out_channels else "transform_first")
         else:
-            raise ValueError('precision must be "bf16x6", "3xbf16" or "fp32"')
+            raise ValueError('precision must be "f16x3", "bf16x6", "3xbf16" or "fp32"')
 
     # the prepared graph holds device tensors; never pickle it with the module
     def __getstate__(self):

@@ -178,7 +178,7 @@ class GNNModel(nn.Module):
         return out
 
     def set_precision(self, precision: str) -> "GNNModel":
-        """"bf16x6" (default), "3xbf16" or "fp32" for every layer (``GCNConv.precision``); returns self."""
+        """"f16x3" (default), "bf16x6", "3xbf16" or "fp32" for every layer (``GCNConv.precision``); returns self."""
         for mod in self.modules():
             if isinstance(mod, GCNConv):
                 mod.precision = precision

@@ -31,13 +31,16 @@ def _rows2d(x: Tensor):
     raise ValueError(f"expected [N, F] or [members, N, F], got {tuple(x.shape)}")
 
 
-AUTO_ORDERS = ("auto", "auto_x3")
+AUTO_ORDERS = ("auto", "auto_x6", "auto_x3")
 
 
 def contract_of_order(order: str) -> str:
-    """Contraction of a layer run under ``order``: "auto" / "fused" -> "bf16x6" (the default, fp32-class),
-    "auto_x3" / "fused_x3" -> "3xbf16", every other (explicit) order -> "fp32"."""
-    if order in ("auto", "fused"):
+    """Contraction of a layer run under ``order``: "auto" -> "f16x3" (the default: fp32-class on the kernel's own
+    split -- K8 from 128 input channels on two scaled fp16 images, every other kernel on bf16x6), "auto_x6" /
+    "fused" -> "bf16x6" in every kernel, "auto_x3" / "fused_x3" -> "3xbf16", every other (explicit) order -> "fp32"."""
+    if order == "auto":
+        return "f16x3"
+    if order in ("auto_x6", "fused"):
         return "bf16x6"
     if order in ("auto_x3", "fused_x3"):
         return "3xbf16"
@@ -50,6 +53,11 @@ def _contract_code(contract, exact: bool = True) -> int:
     if contract not in _lib.CONTRACT_NAMES:
         raise ValueError(f'contract must be one of {sorted(_lib.CONTRACT_NAMES)}')
     return _lib.CONTRACT_NAMES[contract]
+
+
+def _dense_code(contract, exact: bool = True) -> int:
+    """K3 / K4 / K5 / K7: "f16x3" (fp32-class on the kernel's own split) is bf16x6 there."""
+    return _lib.dense_contract(_contract_code(contract, exact))
 
 
 def propagate(graph: GraphCSR, h: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
@@ -105,7 +113,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool 
         _require(bias, "bias")
         bias = bias.contiguous()
     dev = x.device
-    code = _contract_code(contract, exact)
+    code = _dense_code(contract, exact)
     ws = None
     nws = 0 if code == _lib.CONTRACT_F32 else int(_lib.lib().gwen_gcn_linear_workspace_floats(rows, fin, fout))
     if nws > 0:
@@ -176,7 +184,7 @@ def layer_fused(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
         rc = _lib.lib().gwen_gcn_layer_f32(
             _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(weight), _ptr(bias),
             _ptr(out), n, fin, fout, fin, fout, m, n_src * fin, n * fout, int(relu),
-            _contract_code(contract, exact), _stream(dev))
+            _dense_code(contract, exact), _stream(dev))
     _lib.check(rc, "gwen_gcn_layer_f32")
     return out
 
@@ -188,19 +196,21 @@ def wide_supported(fin: int, fout: int) -> bool:
 def wide_preferred(graph: GraphCSR, x: Tensor, fin: int, fout: int, contract: str = "3xbf16") -> bool:
     """Would the stack launcher run this AUTO layer as K8?  (Same rule, so training and inference agree.)"""
     m, n_src, _ = _rows2d(x)
-    code = _contract_code(contract)
+    code = _lib.wide_contract(fin, fout, _contract_code(contract))
     if not _lib.lib().gwen_gcn_wide_preferred(graph.num_nodes, m, fin, fout) or \
             not _lib.lib().gwen_gcn_wide_contract_supported(fin, fout, code):
         return False
     tiles = graph.tiles()
-    return tiles is not None and (code == _lib.CONTRACT_BF16X3 or tiles[3] <= 128)
+    return tiles is not None and (code != _lib.CONTRACT_BF16X6 or tiles[3] <= 128)
 
 
 def wide_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
-               relu: bool = False, contract: str = "3xbf16") -> Tensor:
-    """K8: act((A~ x) W^T + b) in one launch, tile-staged through LDS (widths in {64,128,256}, graphs
-    that tile: ``graph.tiles()``).  ``contract``: "3xbf16", or "bf16x6" for Fin <= 128 on graphs whose tile
-    unions stay within 128 rows; term for term K4's arithmetic."""
+               relu: bool = False, contract: str = "f16x3") -> Tensor:
+    """K8: act((A~ x) W^T + b), tile-staged through LDS (widths in {64,128,256}, graphs that tile:
+    ``graph.tiles()``).  ``contract``: "f16x3" (the library default: fp32-class on two scaled fp16 images from 128
+    input channels, ONE launch at every width; at 64 channels it is bf16x6), "bf16x6" (graphs whose tile unions stay
+    within 128 rows; 256 -> 256 as two 256 -> 128 launches) or "3xbf16" -- the bf16 splits term for term K4's
+    arithmetic."""
     _require(x, "x")
     _require(weight, "weight")
     x = x.contiguous()
@@ -223,8 +233,8 @@ def wide_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor
     with torch.cuda.device(dev):
         rc = _lib.lib().gwen_gcn_wide_layer_f32(
             _ptr(t_rows), _ptr(t_lid), _ptr(t_val), _ptr(x), _ptr(weight), _ptr(bias), _ptr(out),
-            n, n_src, fin, fout, fout, m, n_src * fin, n * fout, int(relu), umax, _contract_code(contract),
-            _stream(dev))
+            n, n_src, fin, fout, fout, m, n_src * fin, n * fout, int(relu), umax,
+            _lib.wide_contract(fin, fout, _contract_code(contract)), _stream(dev))
     _lib.check(rc, "gwen_gcn_wide_layer_f32")
     return out
 
@@ -240,7 +250,7 @@ def small_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tenso
     m, n_src, fin = _rows2d(x)
     n, fout = graph.num_nodes, weight.size(0)
     dense = graph.dense()
-    code = _contract_code(contract)
+    code = _dense_code(contract)
     if dense is None or not _lib.lib().gwen_gcn_small_supported(n, fin, fout, code):
         raise ValueError("K7 needs a square graph of at most 256 nodes, Fin % 32 == 0, Fout % 16 == 0")
     if n_src != n or weight.size(1) != fin:
@@ -277,7 +287,7 @@ def chain(graph: GraphCSR, x: Tensor, w1: Tensor, w2: Optional[Tensor], bias: Op
         rc = _lib.lib().gwen_gcn_chain_f32(
             _ptr(g_rowptr), _ptr(g_col), _ptr(g_val), _ptr(x), _ptr(w1.contiguous()),
             None if w2 is None else _ptr(w2.contiguous()), None if bias is None else _ptr(bias.contiguous()),
-            _ptr(out), n, fin, f1, f2, int(pre), int(relu), m, n * fin, n * fw, _contract_code(contract),
+            _ptr(out), n, fin, f1, f2, int(pre), int(relu), m, n * fin, n * fw, _dense_code(contract),
             _stream(dev))
     _lib.check(rc, "gwen_gcn_chain_f32")
     return out
@@ -341,12 +351,13 @@ class GCNLayerFunction(torch.autograd.Function):
                 relu: bool, order: str, packed: Optional[Tensor] = None) -> Tensor:
         fout, fin = weight.shape
         # one precision rule for both host paths (this Function and the stack launcher, forward.hip): an AUTO
-        # layer contracts with its split ("auto": bf16x6, "auto_x3": 3xbf16) whatever kernels it resolves to;
+        # layer contracts with its split ("auto": f16x3 = K8's scaled fp16 split / bf16x6 in every other kernel,
+        # "auto_x6": bf16x6, "auto_x3": 3xbf16) whatever kernels it resolves to;
         # explicit orders ("transform_first", "aggregate_first", "fused_exact") use the exact fp32-input MFMA
         contract = contract_of_order(order)
         if order in AUTO_ORDERS:
             if graph.dense() is not None and _lib.lib().gwen_gcn_small_supported(graph.num_nodes, fin, fout,
-                                                                                 _contract_code(contract)):
+                                                                                 _dense_code(contract)):
                 order = "small"              # K7: the reference's member graphs (<= 256 nodes)
             elif graph.long_row_levels() is not None:
                 # rows far beyond 8 entries: the fused kernels walk a row serially, the segment chain does not
@@ -365,7 +376,7 @@ class GCNLayerFunction(torch.autograd.Function):
             out = wide_layer(graph, x, weight, bias, relu, contract=contract)
             saved_in = x
         elif order in ("fused", "fused_x3", "fused_exact"):
-            out = layer_fused(graph, x, weight, bias, relu, contract=contract)
+            out = layer_fused(graph, x, weight, bias, relu, contract=contract)          # ("f16x3" is bf16x6 in K4)
             saved_in = x
         elif order == "transform_first":
             h = linear(x, weight, contract=contract)

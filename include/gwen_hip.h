@@ -143,11 +143,18 @@ int gwen_gcn_propagate_f32(const int32_t *rowptr, const int32_t *col, const floa
  *                             accumulation: ~17 bits per product, 7e-6 relative on the 6-layer model;
  *   GWEN_CONTRACT_F32    (1)  fp32-input MFMA: bit-identical to a k-ordered fp32 fmaf chain, 1/16 of the bf16 rate;
  *   GWEN_CONTRACT_BF16X6 (2)  three bf16 images per operand, 6 MFMAs per k-step: 24 bits per operand, fp32-class
- *                             (<= 2e-6 on the 6-layer model) at 6/16 of the fp32 MFMA's cost -- the host API's default.
+ *                             (<= 2e-6 on the 6-layer model) at 6/16 of the fp32 MFMA's cost;
+ *   GWEN_CONTRACT_F16X3  (3)  two fp16 images per operand, both operands scaled by exact powers of two (W per output
+ *                             column, the rows per 64-feature chunk) so that fp16's range holds them: operands kept to
+ *                             2^-24, 3 MFMAs per k-step -- fp32-class at bf16x3's cost.  K8 has it from 128 input
+ *                             channels (gwen_gcn_wide_layer_f32).  On a layer of the stack launcher
+ *                             (gwen_layer_desc.contract) it means "fp32-class on the kernel's own split": K8 runs
+ *                             f16x3, K3 / K4 / K5 / K7 and K8 at 64 channels run bf16x6 -- the host API's default.
  * ------------------------------------------------------------------------------------------- */
 #define GWEN_CONTRACT_BF16X3 0
 #define GWEN_CONTRACT_F32 1
 #define GWEN_CONTRACT_BF16X6 2
+#define GWEN_CONTRACT_F16X3 3
 
 /* ---------------------------------------------------------------------------------------------
  * K3  dense projection == GCNConv.lin (PyG Linear(Fin, Fout, bias=False)):  h = x @ W^T.
@@ -204,8 +211,8 @@ int gwen_gcn_layer_supported(int64_t Fin, int64_t Fout);
  *                                      union exceeds GWEN_TILE_UNION (K8 must not be used: K4 or K3 + K2
  *                                      instead); status[1] = largest union.  T = gwen_gcn_tiles64_count(N).
  * gwen_gcn_wide_layer_f32: x [members, N_src, Fin] contiguous rows, out [members, N, Fout] row stride ldo;
- *   Fin, Fout in {64, 128, 256} (gwen_gcn_wide_supported); N_src * Fin * 4 < 2^32.  3xbf16 contraction,
- *   fp32 accumulation; term for term the arithmetic of gwen_gcn_layer_f32(exact = 0).
+ *   Fin, Fout in {64, 128, 256} (gwen_gcn_wide_supported); N_src * Fin * 4 < 2^32.  Split contraction `contract`,
+ *   fp32 accumulation; the bf16 splits are term for term the arithmetic of gwen_gcn_layer_f32(exact = contract).
  *   union_max = status[1] of gwen_gcn_tiles64 (any upper bound <= GWEN_TILE_UNION is correct): with unions
  *   of at most 128 rows the kernel keeps two chunks of DMA in flight instead of one.
  * ------------------------------------------------------------------------------------------- */
@@ -224,7 +231,8 @@ int gwen_cluster_rows64_host(const int32_t *rowptr, const int32_t *col, int64_t 
 int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout);
 /* contract: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6 for every supported width pair (bf16x6 needs tile unions
  * within 128 rows; at 256 -> 256 it runs as two 256 -> 128 launches: three images of W for all 256 output columns
- * exceed the registers of the 8 waves that hold them). */
+ * exceed the registers of the 8 waves that hold them); GWEN_CONTRACT_F16X3 for Fin in {128, 256}: one launch at every
+ * width, unions up to GWEN_TILE_UNION rows. */
 int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract);
 /* 1 when an AUTO layer of these widths over N rows x members is issued as K8 rather than K4 (given a graph
  * that tiles): every supported width pair with Fin >= 128 (measured 1.15x - 1.6x K4), and Fin = 64 once the
@@ -305,8 +313,9 @@ typedef struct gwen_layer_desc {
   const float *bias;
   int32_t fin, fout, relu, order;
   const void *packed;  /* gwen_gcn_small_pack_f32 image of W for K7, or NULL */
-  int32_t contract;    /* AUTO / FUSED layers: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6 (explicit
-                          transform-first / aggregate-first / FUSED_EXACT orders contract in fp32) */
+  int32_t contract;    /* AUTO / FUSED layers: GWEN_CONTRACT_BF16X3, _BF16X6 or _F16X3 (fp32-class on the kernel's own
+                          split, see above); explicit transform-first / aggregate-first / FUSED_EXACT orders
+                          contract in fp32 */
   int32_t reserved;
 } gwen_layer_desc;
 

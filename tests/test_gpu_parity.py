@@ -429,7 +429,7 @@ def test_kat_complete_graph_is_mean(ga):
     assert rel_err(got, want.expand_as(got)) <= 1e-5
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-6), ("bf16x6", 1e-6), ("3xbf16", 2e-5)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-6), ("f16x3", 1e-6), ("bf16x6", 1e-6), ("3xbf16", 2e-5)])
 def test_kat_path_and_cycle(ga, precision, tol):
     fin = fout = 4
     eye = torch.eye(4)
@@ -636,7 +636,7 @@ def test_precision_switch_train_and_eval_agree(ga):
         with torch.no_grad():
             want = ref(x.double(), ei)
         errs = {}
-        for prec in ("bf16x6", "3xbf16", "fp32"):
+        for prec in ("f16x3", "bf16x6", "3xbf16", "fp32"):
             model.set_precision(prec)
             assert all(c.precision == prec for c in model.modules() if isinstance(c, ga.GCNConv))
             with torch.no_grad():
@@ -649,7 +649,9 @@ def test_precision_switch_train_and_eval_agree(ga):
             errs[prec] = rel_err(ev, want)
             assert errs[prec] <= REL_TOL
         assert errs["fp32"] <= 2e-6 and errs["fp32"] <= errs["3xbf16"]
-        assert errs["bf16x6"] <= 2e-6 and errs["bf16x6"] <= errs["3xbf16"]        # the default is fp32-class
+        assert errs["bf16x6"] <= 2e-6 and errs["bf16x6"] <= errs["3xbf16"]
+        assert errs["f16x3"] <= 2e-6 and errs["f16x3"] <= errs["3xbf16"]          # the default is fp32-class
+    assert ga.GCNConv(8, 8).precision == "f16x3"
     with pytest.raises(ValueError):
         model.set_precision("bf16")
 

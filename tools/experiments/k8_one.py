@@ -1,4 +1,4 @@
-"""One K8 layer, timed:  python tools/experiments/k8_one.py FIN FOUT MEMBERS [3xbf16|bf16x6]  (nu = 100 Hilbert mesh)"""
+"""One K8 layer, timed:  python tools/experiments/k8_one.py FIN FOUT MEMBERS [3xbf16|bf16x6|f16x3]  (nu = 100 Hilbert mesh)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, gwen_amd
