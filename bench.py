@@ -103,6 +103,11 @@ def parse():
                    help="replay a captured hipGraph per step instead of issuing the launches from the C "
                         "launcher (measured slower here: one graph launch costs more than 6 direct ones)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--allow-variant", action="store_true",
+                   help="run although GWEN_HIP_LIB points at an experimental build of the library (the line then "
+                        "carries library.variant = true; such a line is not a measurement of the product)")
+    p.add_argument("--rank-timeout", type=float, default=1500.0,
+                   help="self-launch: wall-clock limit of the ranks; past it they are terminated, then killed")
     p.add_argument("--no-edge-mlp", action="store_true",
                    help="skip the side measurement of the InteractionNet edge-MLP kernel (K6)")
     p.add_argument("--edge-mlp-members", type=int, default=8,
@@ -149,14 +154,18 @@ def launch_plan(n_ranks, argv, port=None, base_env=None):
     return plan
 
 
-def run_plan(plan, poll_s=0.2):
+def run_plan(plan, poll_s=0.2, timeout_s=1500.0, grace_s=10.0):
     """Start every child, wait for all; the first non-zero exit code ends the others (exact PIDs) and is returned.
+    A rank stuck in a collective can not hang the parent: past `timeout_s` of wall clock -- or `grace_s` after the others
+    were told to terminate -- the remaining children are terminated, then killed, and the result is non-zero (124).
     The parent never touches the GPU, so nothing that has initialised HIP is ever re-executed."""
     procs = []
     for argv, env in plan:
         procs.append(subprocess.Popen(argv, env={**os.environ, **env}))
     rc = 0
     live = list(procs)
+    t0 = time.monotonic()
+    term_at = None                    # when the live children were sent SIGTERM
     while live:
         time.sleep(poll_s)
         for p_ in list(live):
@@ -168,6 +177,17 @@ def run_plan(plan, poll_s=0.2):
                 rc = code if code > 0 else 128 - code
                 for q_ in live:
                     q_.terminate()
+                term_at = time.monotonic()
+        now = time.monotonic()
+        if live and term_at is None and now - t0 > timeout_s:
+            rc = rc or 124
+            for q_ in live:
+                q_.terminate()
+            term_at = now
+        elif live and term_at is not None and now - term_at > grace_s:
+            for q_ in live:
+                q_.kill()                                   # exact PIDs of our own children
+            term_at = now
     return rc
 
 
@@ -379,7 +399,7 @@ def init_ranks(args):
             print(json.dumps({"launcher": "bench.py self-launch (one fresh process per GPU)", "n_ranks": args.gpus,
                               "children": [{"argv": a, "env": e} for a, e in plan]}))
             raise SystemExit(0)
-        raise SystemExit(run_plan(plan))
+        raise SystemExit(run_plan(plan, timeout_s=args.rank_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -524,7 +544,9 @@ def run_c5(args, world, rank, dev):
         "edge_updates_per_s": members * r_steps * edges * args.steps / elapsed,
     }
     if allgather is not None:
+        allgather["expected"] = allgather_expectation(allgather["bytes_per_rank"], world)
         line["allgather"] = allgather
+    line["library"] = library_info(args)
     if rank == 0 and world == 1:
         # dominant kernel of the step: K6's edge kernel on the mesh->mesh blocks, by itself on the same batch
         side = edge_mlp_side_measurement(mesh, ch, dev, launches=10, members=m_local)
@@ -588,8 +610,32 @@ def c5_cpu_baseline(IO, model, mesh, graphs, x, out, args, members, elapsed):
             "gpu_vs_oracle_rel_err_one_step": err}
 
 
+def library_info(args):
+    """Which libgwen_hip.so this line was measured on (path + source digest).  A variant build (GWEN_HIP_LIB: the
+    experiment / ablation builds of tools/experiments) is refused unless --allow-variant says the caller knows."""
+    from gwen_amd import _lib
+    if _lib.is_variant() and not args.allow_variant:
+        raise SystemExit(f"GWEN_HIP_LIB={os.environ.get('GWEN_HIP_LIB')} replaces the product library: unset it, or "
+                         f"pass --allow-variant (the line then says library.variant = true)")
+    return _lib.library_stamp()
+
+
+def allgather_expectation(bytes_per_rank, world):
+    """What the one collective should cost on xGMI (point-to-point, 7 links x ~153 GB/s per GPU per the guide): every
+    rank receives (world - 1) shards, in the best case each over its own link."""
+    recv = bytes_per_rank * max(world - 1, 0)
+    links = min(max(world - 1, 1), 7)
+    return {"bytes_per_rank": bytes_per_rank, "bytes_received_per_rank": recv,
+            "expected_us_direct_links": round(bytes_per_rank / 153e9 * 1e6 * max(world - 1, 0) / links, 1),
+            "expected_us_one_link_ring": round(recv / 153e9 * 1e6, 1),
+            "note": "xGMI ~153 GB/s per link and direction, 7 links per GPU (MI355X_MICROARCH.md): between these two "
+                    "figures is healthy; RCCL adds ~20-50 us of launch / protocol latency at small sizes"}
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" in os.environ or args.gpus == 1:
+        library_info(args)                               # refuse a variant library before any work
     world, rank, dev = init_ranks(args)
     if args.workload == "c5":
         return run_c5(args, world, rank, dev)
@@ -702,11 +748,18 @@ def main():
     kind, fin, fout = dom_key
     b_l2 = algorithmic_bytes(kind, n, e, fin, fout) * m_local
     b_comp = compulsory_bytes(kind, n, e, fin, fout, m_local)
-    avg_s = total_s / launches
+    avg_raw = total_s / launches
+    # The brackets over-read (the first kernel of a step by ~2 us: its bracket also holds the launch gap behind the step
+    # before): the kernels of a step can not take longer than the step, so when the per-kernel means sum to more than the
+    # measured step they are scaled down together (bracket_scale < 1; rocprofv3's kernel-only averages agree with the
+    # scaled figures, profiles/)
+    ksum = sum(v[1] / v[0] for v in summ.values())
+    bracket_scale = min(1.0, (elapsed / args.steps) / ksum) if ksum > 0 else 1.0
+    avg_s = avg_raw * bracket_scale
     achieved = b_l2 / avg_s / 1e9
     tag = kernel_tags(kind, fin, fout, {"auto": 3, "unfused": 0, "bf16x3": 2, "fused_exact": 0}[args.order])
     default_c2 = (n, e, c, h, m_local) == (100002, 600000, 64, 64, 1)
-    per_layer_us = {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2) for k, v in sorted(summ.items())}
+    per_layer_us = {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * bracket_scale * 1e6, 2) for k, v in sorted(summ.items())}
     roofline = {
         "bound": "l2", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
         "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / L2_PEAK_GBS, 4),
@@ -716,6 +769,8 @@ def main():
         "compulsory_bytes_per_launch": b_comp,
         "frac_hbm_compulsory": round(b_comp / avg_s / 1e9 / HBM_PEAK_GBS, 4),
         "avg_launch_us": round(avg_s * 1e6, 2), "samples": launches,
+        "avg_launch_us_raw_bracket": round(avg_raw * 1e6, 2), "bracket_scale": round(bracket_scale, 4),
+        "kernel_sum_us": round(ksum * bracket_scale * 1e6, 2),
         "event_record_overhead_us": round(ev_over * 1e6, 2), "all_kernels_us": per_layer_us,
         "why_l2": "the c2 working set (<= 3 x 25.6 MB) never leaves the L2s / Infinity Cache, so HBM does not "
                   "bound this kernel; the HBM-bound measurement of the same path is hbm_leg",
@@ -752,7 +807,9 @@ def main():
         "roofline": roofline,
     }
     if allgather is not None:
+        allgather["expected"] = allgather_expectation(allgather["bytes_per_rank"], world)
         line["allgather"] = allgather
+    line["library"] = library_info(args)
 
     single = rank == 0 and world == 1
     # ---- siblings of the headline on the other contractions (outside the timed region) ----------------------

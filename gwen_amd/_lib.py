@@ -15,7 +15,28 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GWEN_HIP_LIB: an experimental variant build (gwen_amd/build.py::build_variant) instead of the product library --
 # for tools/experiments only; tests and bench.py run with it unset.
-LIB_PATH = os.environ.get("GWEN_HIP_LIB") or os.path.join(_HERE, "libgwen_hip.so")
+PRODUCT_LIB = os.path.join(_HERE, "libgwen_hip.so")
+LIB_PATH = os.environ.get("GWEN_HIP_LIB") or PRODUCT_LIB
+
+
+def is_variant() -> bool:
+    """True when GWEN_HIP_LIB swapped the product library for an experimental build (ablations included: results may
+    be wrong by construction).  tests/conftest.py refuses to run then; bench.py needs --allow-variant and says so."""
+    return os.path.abspath(LIB_PATH) != os.path.abspath(PRODUCT_LIB)
+
+
+def library_stamp() -> dict:
+    """What is loaded: path, and whether the product library's source digest (gwen_amd/build.py) matches the sources."""
+    info = {"path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "variant": is_variant()}
+    try:
+        from . import build as _b
+        with open(PRODUCT_LIB + ".stamp") as fh:
+            stamp = fh.read().strip()
+        info["source_digest"] = stamp[:16]
+        info["matches_sources"] = stamp == _b._digest()
+    except OSError:
+        info["source_digest"] = None
+    return info
 
 _lib = None
 _lock = threading.Lock()
@@ -107,7 +128,7 @@ SIGNATURES = {
                                     _vp, _i64, _i64, _vp, C.POINTER(C.c_void_p),
                                     C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_void_p)]),
-    "gwen_gcn_layer_bwd_f32": (_int, [_vp] * 8 + [_i64] * 4 + [_vp]),
+    "gwen_gcn_layer_bwd_f32": (_int, [_vp] * 8 + [_i64] * 4 + [_int, _vp]),
     "gwen_gnn_backward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
     "gwen_gnn_backward_f32": (_int, [C.POINTER(GraphDesc), C.POINTER(LayerDesc), C.c_int32, _vp,
                                      C.POINTER(C.c_void_p), _vp, _vp, C.POINTER(C.c_void_p),

@@ -121,16 +121,17 @@ extern "C" int gwen_gnn_backward_f32(const gwen_graph *graph_t, const gwen_layer
     }
     const bool fused = need_gx && have_grouped && gwen_gcn_layer_supported(fo, fi) &&
                        (L.order == GWEN_ORDER_AUTO || L.order == GWEN_ORDER_FUSED);
+    // the layer's own precision: bf16x3 layers contract gx on bf16x3, fp32-class layers (bf16x6,
+    // f16x3) on bf16x6, explicit / fp32 orders on the fp32-input MFMA (K3 below)
+    const int cc = gwen_dense_contract(gwen_contract_of(L));
     if (fused) {
       GWEN_TRY(gwen_gcn_layer_bwd_f32(graph_t->g_rowptr, graph_t->g_col, graph_t->g_val, g, wt, mask, gh,
-                                      gx, N, fo, fi, members, stream));
+                                      gx, N, fo, fi, members, cc, stream));
     } else {
       GWEN_TRY(gwen_gcn_propagate_f32(graph_t->rowptr, graph_t->col, graph_t->val, g, nullptr, gh, N, fo,
                                       fo, fo, members, N * fo, N * fo, 0, stream));
       if (need_gx) {
-        GWEN_TRY(gwen_gcn_linear_f32(gh, wt, nullptr, gx, rows, fo, fi, fo, fi, 0,
-                                     L.order != GWEN_ORDER_AUTO && L.order != GWEN_ORDER_FUSED, nullptr, 0,
-                                     stream));
+        GWEN_TRY(gwen_gcn_linear_f32(gh, wt, nullptr, gx, rows, fo, fi, fo, fi, 0, cc, nullptr, 0, stream));
         if (mask) GWEN_TRY(gwen_relu_backward_f32(mask, gx, gx, rows * fi, stream));
       }
     }

@@ -26,6 +26,17 @@ static inline bool gwen_aligned(const void *p, size_t a) {
   return (reinterpret_cast<uintptr_t>(p) % a) == 0;
 }
 
+// contraction of a layer's dense part in the stack launchers (forward.hip, backward.hip): AUTO / FUSED layers carry it
+// (bf16x3, bf16x6 or f16x3), explicit orders are fp32
+static inline int gwen_contract_of(const gwen_layer_desc &L) {
+  if (L.order == GWEN_ORDER_AUTO || L.order == GWEN_ORDER_FUSED)
+    return L.contract == GWEN_CONTRACT_BF16X6 || L.contract == GWEN_CONTRACT_F16X3 ? L.contract : GWEN_CONTRACT_BF16X3;
+  return GWEN_CONTRACT_F32;
+}
+// GWEN_CONTRACT_F16X3 on a layer = "fp32-class, the kernel's own split": K8 has the scaled fp16 split from 128 input
+// channels; every other kernel (K3, K4, K5, K7, the backward, and K8 at 64 channels) runs its fp32-class split, bf16x6
+static inline int gwen_dense_contract(int c) { return c == GWEN_CONTRACT_F16X3 ? GWEN_CONTRACT_BF16X6 : c; }
+
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -22,15 +22,8 @@ inline int resolve_order(const gwen_layer_desc &L) {
   return L.order;
 }
 
-// contraction of a layer's dense part: AUTO / FUSED layers carry it (bf16x3, bf16x6 or f16x3), explicit orders are fp32
-inline int contract_of(const gwen_layer_desc &L) {
-  if (L.order == GWEN_ORDER_AUTO || L.order == GWEN_ORDER_FUSED)
-    return L.contract == GWEN_CONTRACT_BF16X6 || L.contract == GWEN_CONTRACT_F16X3 ? L.contract : GWEN_CONTRACT_BF16X3;
-  return GWEN_CONTRACT_F32;
-}
-// GWEN_CONTRACT_F16X3 on a layer = "fp32-class, the kernel's own split": K8 has the scaled fp16 split from 128 input
-// channels; every other kernel (K3, K4, K5, K7, and K8 at 64 channels) runs its fp32-class split, bf16x6
-inline int dense_contract(int c) { return c == GWEN_CONTRACT_F16X3 ? GWEN_CONTRACT_BF16X6 : c; }
+inline int contract_of(const gwen_layer_desc &L) { return gwen_contract_of(L); }           // (common.h)
+inline int dense_contract(int c) { return gwen_dense_contract(c); }
 inline int wide_contract(int c, int64_t fi, int64_t fo) {
   return c == GWEN_CONTRACT_F16X3 && !gwen_gcn_wide_contract_supported(fi, fo, c) ? GWEN_CONTRACT_BF16X6 : c;
 }

@@ -28,11 +28,12 @@ __device__ inline float act_fwd(float x, int act, float &d) {
   return x;
 }
 
-// h = act(pre), dact = act'(pre), pre = a + g1[idx1 or row] + g2[idx2 or row]; one thread per 4 columns
-__global__ __launch_bounds__(256) void k_act_pair(const float *__restrict__ a, const float *__restrict__ g1,
+// h = act(pre), dact = act'(pre), pre = a + g1[idx1 or row] + g2[idx2 or row]; one thread per 4 columns.
+// h may be a (in place: every thread loads its 4 elements before it stores them) -- so neither is __restrict__
+__global__ __launch_bounds__(256) void k_act_pair(const float *a, const float *__restrict__ g1,
                                                   const int32_t *__restrict__ idx1, int64_t ld1,
                                                   const float *__restrict__ g2, const int32_t *__restrict__ idx2,
-                                                  int64_t ld2, float *__restrict__ h, float *__restrict__ dact,
+                                                  int64_t ld2, float *h, float *__restrict__ dact,
                                                   int64_t rows, int F4, int act) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= rows * F4) return;
@@ -52,10 +53,10 @@ __global__ __launch_bounds__(256) void k_act_pair(const float *__restrict__ a, c
   if (dact) *reinterpret_cast<float4_t *>(dact + r * (int64_t)(F4 * 4) + c) = d;
 }
 
-// out[r] = (a ? a[r] : 0) + t[idx[r]] * (scale ? scale[idx[r]] : 1)
-__global__ __launch_bounds__(256) void k_gather_add(const float *__restrict__ a, const float *__restrict__ t,
+// out[r] = (a ? a[r] : 0) + t[idx[r]] * (scale ? scale[idx[r]] : 1); out may be a (in place, as above)
+__global__ __launch_bounds__(256) void k_gather_add(const float *a, const float *__restrict__ t,
                                                     const int32_t *__restrict__ idx,
-                                                    const float *__restrict__ scale, float *__restrict__ out,
+                                                    const float *__restrict__ scale, float *out,
                                                     int64_t rows, int F4) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= rows * F4) return;
@@ -71,8 +72,7 @@ __global__ __launch_bounds__(256) void k_gather_add(const float *__restrict__ a,
   *reinterpret_cast<float4_t *>(out + r * (int64_t)(F4 * 4) + c) = v;
 }
 
-__global__ __launch_bounds__(256) void k_ew(int op, const float *__restrict__ a, const float *__restrict__ b,
-                                            float *__restrict__ out, int64_t n4) {
+__global__ __launch_bounds__(256) void k_ew(int op, const float *a, const float *b, float *out, int64_t n4) {   // out may be a or b
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const float4_t x = reinterpret_cast<const float4_t *>(a)[i], y = reinterpret_cast<const float4_t *>(b)[i];

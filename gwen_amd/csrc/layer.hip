@@ -213,7 +213,7 @@ int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, con
   int64_t blocks = (N + C::BR - 1) / C::BR;
   if (FIN * FOUT >= 128 * 128 && blocks > resident) blocks = resident;   // wide layer: one resident set
   dim3 grid((unsigned)blocks, (unsigned)members);
-  if constexpr (NS == 2) {          // the backward runs on the bf16x3 contraction
+  if constexpr (NS == 2 || NS == 3) {          // the backward runs on the layer's own split (bf16x3 / bf16x6)
     if (bwd) {
       if (!rowptr)
         k_layer<FIN, FOUT, NS, BRMIN, true, true><<<grid, C::NWB * 64, 0, st>>>(
@@ -329,8 +329,8 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
 extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
                                       const float *g, const float *Wt, const float *mask, float *gh,
                                       float *gx, int64_t N, int64_t Fg, int64_t Fx, int64_t members,
-                                      gwen_stream_t stream_) {
-  if (N < 0 || members < 0) return GWEN_EINVAL;
+                                      int contract, gwen_stream_t stream_) {
+  if (N < 0 || members < 0 || (contract != GWEN_CONTRACT_BF16X3 && contract != GWEN_CONTRACT_BF16X6)) return GWEN_EINVAL;
   if (!gwen_gcn_layer_supported(Fg, Fx)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
   if (!t_col || !t_val || !g || !Wt || !gx || g == gx) return GWEN_EINVAL;
@@ -342,8 +342,11 @@ extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_
   hipStream_t st = gwen_stream(stream_);
 #define GWEN_L(FI, FO)                                                                           \
   if (Fg == FI && Fx == FO)                                                                      \
-    return launch<FI, FO, 2>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,        \
-                                N * Fg, N * Fx, 0, st, gh, mask, true)
+    return contract == GWEN_CONTRACT_BF16X6                                                      \
+               ? launch<FI, FO, 3>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,  \
+                                   N * Fg, N * Fx, 0, st, gh, mask, true)                        \
+               : launch<FI, FO, 2>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,  \
+                                   N * Fg, N * Fx, 0, st, gh, mask, true)
   GWEN_L(16, 16); GWEN_L(16, 32); GWEN_L(16, 64); GWEN_L(16, 128);
   GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);
   GWEN_L(64, 16); GWEN_L(64, 32); GWEN_L(64, 64); GWEN_L(64, 128);

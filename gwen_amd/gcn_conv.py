@@ -85,8 +85,8 @@ class GCNConv(nn.Module):
         other kernel into three bf16 images (six terms); "bf16x6": three bf16 images in every kernel (K8 at 256 -> 256
         then runs two launches); "3xbf16": the faster two-image split (~17 bits per product, 7e-6 on the model; meets the 1e-4 contract);
         "fp32": the fp32-input MFMA (exact fp32 products, bit-identical to a k-ordered fmaf chain).  The same
-        rule holds in training (forward; the backward contracts with "3xbf16") and inference, in the per-layer
-        path and in the stack launcher."""
+        rule holds in training (forward AND backward: gradients contract on the layer's own precision, "f16x3" layers
+        on bf16x6) and inference, in the per-layer path and in the stack launcher."""
         from .ops import contract_of_order
         return contract_of_order(self.order)
 

@@ -389,6 +389,7 @@ class GCNLayerFunction(torch.autograd.Function):
         else:
             raise ValueError(f"unknown order {order!r}")
         ctx.graph, ctx.relu, ctx.order, ctx.has_bias = graph, relu, order, bias is not None
+        ctx.contract = contract          # the backward contracts on the layer's own precision ("f16x3": bf16x6 in K3)
         ctx.save_for_backward(saved_in, weight, out if relu else None)
         return out
 
@@ -405,12 +406,12 @@ class GCNLayerFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in)                     # gh^T x
             if ctx.needs_input_grad[0]:
-                gx = linear(gh, weight.t().contiguous(), exact=False)          # gh W (3xbf16, split-K)
+                gx = linear(gh, weight.t().contiguous(), contract=ctx.contract)        # gh W (split-K)
         else:
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(g, saved_in)                      # g^T (A~ x)
             if ctx.needs_input_grad[0]:
-                gagg = linear(g, weight.t().contiguous(), exact=False)         # g W
+                gagg = linear(g, weight.t().contiguous(), contract=ctx.contract)       # g W
                 gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)
         return gx, gw, gb, None, None, None, None
 

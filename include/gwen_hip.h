@@ -416,10 +416,12 @@ int gwen_transpose_batched(const float *const *w, float *const *wt, const int32_
  *     gh = A~^T g                         stored (the operand of grad_W = gh^T x); gh may be NULL
  *     gx = (gh Wt^T) masked by mask > 0   Wt [Fx, Fg] = the layer's lin.weight ([Fg, Fx]) transposed;
  *                                         mask = the output of the layer below when it has a ReLU, or NULL
- *   g, gh [members, N, Fg]; gx, mask [members, N, Fx], contiguous; widths as gwen_gcn_layer_supported(Fg, Fx).
+ *   g, gh [members, N, Fg]; gx, mask [members, N, Fx], contiguous; widths as gwen_gcn_layer_supported(Fg, Fx);
+ *   contract: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6 -- the split of the gx contraction.
  * gwen_gnn_backward_f32: all layers, last to first, from one host call: per layer grad_b (column sums of
  *   the incoming, already masked gradient), the launch above (or K2^T + K3 + mask where the widths are not
- *   K4's), grad_W.  graph_t: the views of the TRANSPOSED graph (rowptr/col/val and, for the fused launch,
+ *   K4's) on the LAYER'S OWN precision (bf16x3 layers: bf16x3; bf16x6 / f16x3 layers: bf16x6; explicit fp32
+ *   orders: the fp32-input MFMA), grad_W (fp32-input MFMA reductions).  graph_t: the views of the TRANSPOSED graph (rowptr/col/val and, for the fused launch,
  *   g_rowptr/g_col/g_val).  acts (HOST array of n_layers device pointers): every layer's output as the
  *   training forward stored it (gwen_gnn_forward_f32 with acts); x: the stack's input; grad_out: gradient of
  *   the last layer's output.  grad_x may be NULL; grad_W / grad_b: HOST arrays of device pointers (NULL array
@@ -427,7 +429,7 @@ int gwen_transpose_batched(const float *const *w, float *const *wt, const int32_
  * ------------------------------------------------------------------------------------------- */
 int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
                            const float *g, const float *Wt, const float *mask, float *gh, float *gx,
-                           int64_t N, int64_t Fg, int64_t Fx, int64_t members, gwen_stream_t stream);
+                           int64_t N, int64_t Fg, int64_t Fx, int64_t members, int contract, gwen_stream_t stream);
 int64_t gwen_gnn_backward_scratch_floats(int64_t N, int64_t members, const struct gwen_layer_desc *layers,
                                          int32_t n_layers);
 int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_layer_desc *layers,

@@ -98,6 +98,31 @@ def test_self_launch_runs_children_and_propagates_failure():
     assert time.perf_counter() - t0 < 30
 
 
+def test_self_launch_kills_a_rank_that_hangs():
+    """A rank stuck in a collective must not hang the parent: past the wall-clock limit the ranks are terminated, one
+    that ignores SIGTERM is killed after the grace period, and the result is non-zero."""
+    import bench
+    import time
+    hang = [([sys.executable, "-c", "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(120)"],
+             {"RANK": "0"}),
+            ([sys.executable, "-c", "import time; time.sleep(120)"], {"RANK": "1"})]
+    t0 = time.perf_counter()
+    assert bench.run_plan(hang, poll_s=0.05, timeout_s=1.0, grace_s=1.0) == 124
+    assert time.perf_counter() - t0 < 30
+
+
+def test_variant_library_is_refused(tmp_path):
+    """GWEN_HIP_LIB (an experimental / ablated build) must not produce a bench line or a green test run unasked."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GWEN_HIP_LIB"] = str(tmp_path / "libgwen_hip.other.so")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "GWEN_HIP_LIB" in (out.stderr + out.stdout)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_abi.py"), "-q", "-x"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "GWEN_HIP_LIB" in (out.stderr + out.stdout)
+
+
 def test_c5_workload_defaults(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "c5"])

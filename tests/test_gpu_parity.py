@@ -529,11 +529,14 @@ def test_model_training_step(ga):
 # ------------------------------------------------------------------------------------------------
 # whole-stack training path: gwen_gnn_forward_f32 (acts) + gwen_gnn_backward_f32, one host call each
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,GRAD_TOL", [("f16x3", 1e-5), ("3xbf16", 1e-4)])
 @pytest.mark.parametrize("members", [1, 3])
 @pytest.mark.parametrize("C,H", [(64, 64), (8, 16), (20, 48), (32, 128), (16, 256)])
-def test_stack_backward_vs_oracle_autograd(ga, C, H, members):
+def test_stack_backward_vs_oracle_autograd(ga, C, H, members, precision, GRAD_TOL):
     """Every gradient of GNNModel (x, 6 weights, 6 biases) through the stack launchers against torch autograd
-    on the CPU oracle -- widths K4's backward kernel takes (fused launch) and widths it does not (K2^T + K3)."""
+    on the CPU oracle -- widths K4's backward kernel takes (fused launch) and widths it does not (K2^T + K3).
+    The backward contracts on the layer's own precision: 1e-5 on the fp32-class default (the reference's fp32
+    autograd through loss.backward(), /root/reference/src/gwen/models_gnn.py:372), 1e-4 on the "3xbf16" tier."""
     from oracle import gcn_oracle as O
     m = ga.geodesic_mesh(7, reorder="hilbert")
     n = m.num_nodes                                     # 492 > 256: not the K7 path
@@ -546,7 +549,7 @@ def test_stack_backward_vs_oracle_autograd(ga, C, H, members):
                 p.normal_(0, 0.1)
     model = ga.GNNModel(ga.GNNConfig(n, n, C, C, H))
     model.load_state_dict(ref.state_dict(), strict=True)
-    model = model.to(DEV)
+    model = model.to(DEV).set_precision(precision)
     x = torch.randn(members, n, C, generator=torch.Generator().manual_seed(SEED))
     gout = torch.randn(members, n, C, generator=torch.Generator().manual_seed(SEED + 1))
     xr = x.clone().requires_grad_()
@@ -579,14 +582,14 @@ def test_stack_backward_vs_oracle_autograd(ga, C, H, members):
         .backward(gout.double())
     got = dict(model.named_parameters())
     for k in range(members):
-        assert l2_err(xd.grad.view(members, n, C)[k], xm.grad[k]) <= REL_TOL, (k, "grad_x")
-        assert rel_err(xd.grad.view(members, n, C)[k], xm.grad[k]) <= REL_TOL, (k, "grad_x max")
+        assert l2_err(xd.grad.view(members, n, C)[k], xm.grad[k]) <= GRAD_TOL, (k, "grad_x")
+        assert rel_err(xd.grad.view(members, n, C)[k], xm.grad[k]) <= GRAD_TOL, (k, "grad_x max")
     for name, p in ref64.named_parameters():
         if p.grad is None:
             assert got[name].grad is None, name
         else:
-            assert l2_err(got[name].grad, p.grad) <= REL_TOL, name
-            assert rel_err(got[name].grad, p.grad) <= REL_TOL, name
+            assert l2_err(got[name].grad, p.grad) <= GRAD_TOL, name
+            assert rel_err(got[name].grad, p.grad) <= GRAD_TOL, name
     # SECONDARY sanity bound against the oracle's OWN patterns (what the reference's training would compute):
     # flipped units move a member's gradient by 1e-4..1e-2 in their neighbourhood, never more
     errs = sorted(l2_err(xd.grad.view(members, n, C)[k], xr.grad[k]) for k in range(members))
@@ -603,6 +606,36 @@ def test_stack_backward_vs_oracle_autograd(ga, C, H, members):
     assert rel_err(xd2.grad, xd.grad) <= 2e-5          # same forward values, same masks: rounding order only
     for k, v in stack_grads.items():
         assert rel_err(got[k].grad, v) <= 2e-5, k
+
+
+@pytest.mark.parametrize("contract,tol", [("bf16x6", 2e-6), ("f16x3", 2e-6), ("3xbf16", 2e-5), ("fp32", 2e-6)])
+@pytest.mark.parametrize("rows,fin,fout", [((700,), 64, 64), ((3, 211), 6, 64), ((1000,), 256, 10), ((5, 40), 30, 7)])
+@pytest.mark.parametrize("relu,use_bias", [(False, True), (True, True), (True, False)])
+def test_linear_autograd_vs_fp64(ga, contract, tol, rows, fin, fout, relu, use_bias):
+    """ops.linear_autograd (K3 with the hand-written backward: g_x = g W, g_W = g^T x, g_b = column sums, ReLU mask on
+    y) against fp64 torch autograd -- 2-D and 3-D inputs, widths the vector K3 path does not take (Fin = 6, 30), with
+    and without bias / ReLU.  (The forecaster's embedding and read-out train through it.)"""
+    from gwen_amd import ops
+    g = torch.Generator().manual_seed(SEED)
+    x = torch.randn(*rows, fin, generator=g)
+    w, b = make_params(fin, fout)
+    gout = torch.randn(*rows, fout, generator=g)
+    xd = x.to(DEV).requires_grad_()
+    wd = w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if use_bias else None
+    y = ops.linear_autograd(xd, wd, bd, relu=relu, contract=contract)
+    y.backward(gout.to(DEV))
+    x64, w64 = x.double().requires_grad_(), w.double().requires_grad_()
+    b64 = b.double().requires_grad_() if use_bias else None
+    pre = torch.nn.functional.linear(x64, w64, b64)
+    # differentiate the fp64 expression at the DEVICE's ReLU pattern (a unit within rounding of zero may fall either side)
+    y64 = pre * (y.detach().cpu() > 0).double() if relu else pre
+    y64.backward(gout.double())
+    assert rel_err(y.detach(), y64.detach()) <= tol
+    assert rel_err(xd.grad, x64.grad) <= tol
+    assert rel_err(wd.grad, w64.grad) <= tol
+    if use_bias:
+        assert rel_err(bd.grad, b64.grad) <= tol
 
 
 def test_stack_backward_without_input_grad_and_determinism(ga):
