@@ -48,86 +48,19 @@
 #include "split.h"
 #include <type_traits>
 
-#ifndef WEAVE_VALU
-#define WEAVE_VALU 2
-#endif
-#ifndef K8_ROLES      // -1: where it measured faster (Fin = 64); 0 / 1: never / always (variant builds)
-#define K8_ROLES (-1)
-#endif
-#ifndef K8_PRIO       // experiment: s_setprio around the MFMA half
-#define K8_PRIO 0
-#endif
-#ifndef K8_ABL_NOWLO  // TIMING ABLATION (results wrong by construction): W's second image is not kept -- what would
-#define K8_ABL_NOWLO 0 // 16 waves at Fin = 256 buy if W's low image did not occupy registers?  (-DK8_ABL_NOWLO=1)
-#endif
-#ifndef K8_D          // chunks of DMA in flight behind the one being aggregated (bf16x3, unions <= 128 rows): 1, 2, or
-#define K8_D (-1)     // -1 = what measured fastest per width (2 at Fin = 64, 1 above)
-#endif
-#ifndef K8_D6         // the same for bf16x6 (two chunks need the 144-B A pitch to fit the LDS): -1 = 2 at Fin = 64, 1 above
-#define K8_D6 (-1)
-#endif
-#ifndef K8_NT_LD      // 1: non-temporal staging loads too (variant builds; measured: see glds16_p)
-#define K8_NT_LD 0
-#endif
-#ifndef K8_LD_POLICY  // experiment: cache policy of the staging DMAs (" nt", " sc1", ...)
-#define K8_LD_POLICY ""
-#endif
-#ifndef K8_SHIFT      // 1: the vector work of an aggregate stage runs ONE REGION AFTER the stage's LDS reads (two row
-#define K8_SHIFT 1    // buffers), so the reads' latency sits behind a region of MFMAs instead of in front of the first woven fma
-#endif
-#ifndef K8_STAMP      // DIAGNOSTIC build (-DK8_STAMP=1, tools/experiments/k8_stamp.py): block K8_STAMP_BLOCK's waves record
-#define K8_STAMP 0    // s_memtime at five points of 32 steps into LDS and dump them to gwen_k8_stamp_buf at the end
-#endif
-#ifndef K8_STAMP_BLOCK
-#define K8_STAMP_BLOCK 9
-#endif
-#ifndef K8_ABL_NOSTORE  // TIMING ABLATION (no output): what do the spread stores of a finished tile cost the step they ride in?
-#define K8_ABL_NOSTORE 0
-#endif
-#ifndef K8_ABL_STORE_LOCAL
-#define K8_ABL_STORE_LOCAL 0
-#endif
-#ifndef K8_SKEW       // 1: at 4 chunks per tile, row tile t of a tile runs t steps behind row tile 0 (its A slices wait in a
-#define K8_SKEW 1     // ring), so ONE row tile finishes per step and the output stores are spread over every step
-#endif
-#ifndef K8_EARLYR     // 1: row ids of the next step's chunk loaded behind this step's last DMA (see EARLYR)
-#define K8_EARLYR 1
-#endif
-#ifndef K8_EARLYR_U   // the region that issues them (8 regions per step where EARLYR applies; -1: the one behind the last DMA)
-#define K8_EARLYR_U 6     // (measured: 205.5-207 us against 208.8 with region 4, 207.5-208 with region 7)
-#endif
-#ifndef K8_SBIAS      // 1: SKEW reads a store's bias fragment one region ahead
-#define K8_SBIAS 1
-#endif
-#ifndef K8_PREF_ROWS  // rows x members from which the planner takes K8 at 64 channels (below: K4; re-measured in round 3, see there)
-#define K8_PREF_ROWS 300000
-#endif
-#ifndef K8_X6_128_NW8   // bf16x6 at 128 input channels: 8 waves of 256 registers instead of 16 of 128, by Fout (bit 0: 64,
-#define K8_X6_128_NW8 4 // bit 1: 128, bit 2: 256).  128 -> 256 on 16 waves spills 9-14 registers: 464 us against 376 (8 members)
-#endif
-#ifndef K8_VOFFQ      // 1: DMA row offsets computed once per tile (see VOFFQ)
-#define K8_VOFFQ 1
-#endif
-#ifndef K8_PERM       // 1: a gathered row's LDS address by one v_perm_b32 (see PERM)
-#define K8_PERM 1
-#endif
-#ifndef K8_NT         // -1: by working-set size (launcher); 0 / 1: never / always (variant builds)
-#define K8_NT (-1)
-#endif
-
-#if K8_STAMP
-__device__ uint32_t gwen_k8_stamp_buf[16 * 32 * 8];       // [wave][step][point]
-extern "C" int gwen_k8_stamps_read(uint32_t *host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gwen_k8_stamp_buf), sizeof(gwen_k8_stamp_buf));
-}
-// (waited for inside the statement: hipcc takes the output as written at once, and a result landing later would clobber
-//  whatever the register pair holds by then -- a pointer, once the stamps push the kernel past its SGPR budget)
-#define K8_TS(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[k]) :: "memory")
-#else
-#define K8_TS(k)
-#endif
-
 namespace {
+
+// ---- choices of the shipped kernel, each the winner of an A/B on one box (DESIGN.md section 4 "K8" has the numbers; the
+// lab version of this file -- timing ablations, in-kernel s_memtime stamps, the dropped alternatives as -D knobs -- is
+// tools/experiments/wide_lab.patch, applied on top of this file by tools/experiments/k8_variants.sh) ------------------
+constexpr int kWeaveValu = 2;        // vector instructions woven behind every MFMA of a region
+constexpr int kEarlyRegion = 6;      // the region that loads the next tile's row ids (205.5-207 us; region 4: 208.8, 7: 207.5-208)
+constexpr int kPrefRows = 300000;    // rows x members from which the planner takes K8 at 64 channels (below: K4)
+// chunks of DMA in flight behind the one being aggregated: 2 at 64 channels (a step is one whole tile and short), 1 above
+constexpr int dma_depth(int fin) { return fin == 64 ? 2 : 1; }
+// bf16x6 at 128 input channels: 8 waves of 256 registers for 128 -> 256 (16 waves spill 9-14 there: 464 us against 376 on
+// 8 members), 16 waves of 128 for 128 -> 64 / 128
+constexpr int x6_waves_128(int fout) { return fout == 256 ? 8 : 16; }
 
 using gwen::bf16x4;
 using gwen::bf16x8;
@@ -153,9 +86,6 @@ __device__ inline void split4n(const float4_t &a, bf16x4 (&im)[NS]) {
   gwen::split_images<4, NS>(f4, im);
 }
 
-#ifndef K8_RELU_IMAX  // 1: ReLU as a signed-integer max on the float's bits (one instruction per element)
-#define K8_RELU_IMAX 1
-#endif
 // ReLU of four values.  `x < 0 ? 0 : x` keeps NaN (as torch.relu does) but is a compare + select per element;
 // max(bits(x), 0) on the bits as SIGNED integers is one v_max_i32: a float with the sign bit clear is a
 // non-negative integer and stays, one with the sign bit set is a negative integer and becomes +0 -- identical for
@@ -163,27 +93,16 @@ __device__ inline void split4n(const float4_t &a, bf16x4 (&im)[NS]) {
 // 0 * Inf give 0x7fc00000 on gfx950) stays a NaN; only a NaN carrying a SET sign bit would read as 0.
 // `floor_bits` = 0 with the ReLU, INT_MIN without (max with INT_MIN changes nothing): no branch, no select.
 __device__ inline float4_t relu4(float4_t v, int relu, int floor_bits) {
-#if K8_RELU_IMAX
   typedef int int4_t __attribute__((ext_vector_type(4)));
   int4_t b = __builtin_bit_cast(int4_t, v);
 #pragma unroll
   for (int e = 0; e < 4; ++e) b[e] = b[e] > floor_bits ? b[e] : floor_bits;
   return __builtin_bit_cast(float4_t, b);
-#else
-  if (relu) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
-  }
-  return v;
-#endif
 }
 
-#ifndef K8_FMA        // 0: vector fma (hipcc emits v_pk_fma_f32 + a move per weight); 1: four v_fma_f32, weight as an
-#define K8_FMA 1      // operand -- 1.3-1.7 % faster at 256 channels (245.0 / 242.6 vs 248.2 / 246.8 us, A/B on one box), equal at 64
-#endif
-// acc + w * v on four lanes of a row (fused: one rounding per element either way, the same bits)
+// acc + w * v on four lanes of a row, as four v_fma_f32 with the weight as an operand (the vector form makes hipcc emit
+// v_pk_fma_f32 + a move per weight: 1.3-1.7 % slower at 256 channels, A/B on one box; the same bits either way)
 __device__ inline float4_t fma4(float w, const float4_t &v, float4_t acc) {
-#if K8_FMA == 1
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float r = acc[e];
@@ -191,9 +110,6 @@ __device__ inline float4_t fma4(float w, const float4_t &v, float4_t acc) {
     acc[e] = r;
   }
   return acc;
-#else
-  return __builtin_elementwise_fma(float4_t{w, w, w, w}, v, acc);
-#endif
 }
 
 template <int N, typename F, int I = 0>
@@ -214,21 +130,13 @@ __device__ inline const char *uniform_ptr(const void *p) {
 }
 
 // one LDS-DMA wave instruction: lane l copies 16 B from base + voff(l) to LDS byte address dst + 16 l.
-// nt: non-temporal cache policy for the staging loads (-DK8_NT_LD=1; off in the product).  Measured in the 4-layer
-// stacks, two A/B repeats on one box: 64 -> 64 x 16 members bf16x6 214.4 -> 209.1 us, but bf16x3 198.0 -> 203.0 and
-// 256 -> 256 x 4 members 242.0 -> 249.2: the halo rows neighbouring tiles share are re-read from L2 shortly after,
-// and nt lines leave it first.
-template <bool NT>
-__device__ inline void glds16_p(const void *base, uint32_t voff, uint32_t dst) {
+// (non-temporal staging loads measured slower where it matters -- 256 -> 256 x 4 members 242.0 -> 249.2 us, 64 -> 64 x 16
+//  bf16x3 198.0 -> 203.0: the halo rows neighbouring tiles share are re-read from L2 shortly after, and nt lines leave first)
+__device__ inline void glds16(const void *base, uint32_t voff, uint32_t dst) {
   uint32_t keep;       // M0 is compiler-reserved: save and restore it inside the statement
-  if constexpr (NT)
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
-  else
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2" K8_LD_POLICY "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
@@ -260,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
     int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu, int32_t ldx, int nt) {
   // ROLES (below): the two waves of a SIMD take the step's two halves in opposite order
-  constexpr bool ROLES = (K8_ROLES < 0 ? (FIN == 64 && D == 1) : K8_ROLES != 0) && !DENSE && (D == 1 || D == 2);
+  constexpr bool ROLES = FIN == 64 && D == 1 && !DENSE;      // (measured faster there only; 256 channels: 267.7 vs 265.5 us)
   constexpr int NSTG = D + 1;                           // stage buffers
   constexpr int kStageBytes = KU * kFC * 4;
   constexpr int NC = FIN / kFC;                         // chunks per tile
@@ -283,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   // stores at ~32 GB/s and the in-order waves stand behind them.  The aggregate of a chunk is kept per ROW TILE in a
   // ring of t + 2 slices (written in step s' - 1, read in step s' + t): 14 slices of 5 KiB instead of 2 chunks of 20.
   // (the dense form -- K3's tall case, two chunks of DMA in flight over 64-slot buffers -- takes the same schedule)
-  constexpr bool SKEW = K8_SKEW && !ROLES && NC == 4 && NTT == 4 && TSTEP == 1 && NS == 2 &&
+  constexpr bool SKEW = !ROLES && NC == 4 && NTT == 4 && TSTEP == 1 && NS == 2 &&
                         (DENSE ? (D == 2 && KU == kRows) : (D == 1 && KU == 128));
   constexpr int kSlImg = 16 * kPB * 2, kSl = NS * kSlImg;        // one image / all images of a row tile's slice of a chunk
   constexpr int kImgStride = SKEW ? kSlImg : kAImg;
@@ -294,15 +202,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   constexpr int kSide = kFC * 2;                        // F16: byte offset of a row's {e, delta} in its first image's row
   auto ring_base = [](int ti) { return (ti * (ti + 3) / 2) * kSl; };     // rings of 2, 3, 4, 5 slices: first slice 0, 2, 5, 9
   static_assert(kLds <= 160 * 1024, "the block's LDS exceeds a CU's");
-  constexpr int kStampBytes = K8_STAMP && kLds + NW * 1024 <= 160 * 1024 ? NW * 1024 : 0;   // (diagnostic build, where it fits)
   static_assert(!DENSE || KU == kRows, "a dense tile stages its own rows");
   const uint32_t row_pitch = DENSE ? (uint32_t)ldx * 4u : (uint32_t)(FIN * 4);
   const int floor_bits = relu ? 0 : (int)0x80000000;     // relu4
-  auto glds16 = [&](const void *base, uint32_t voff, uint32_t dst) {     // nt is wave-uniform (a kernel argument)
-    if (nt && K8_NT_LD) glds16_p<true>(base, voff, dst);
-    else glds16_p<false>(base, voff, dst);
-  };
-  __shared__ __attribute__((aligned(1024))) char lds[kLds + kStampBytes];
+  __shared__ __attribute__((aligned(1024))) char lds[kLds];
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int mi = lane & 15, mh = lane >> 4;
@@ -331,8 +234,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   // ---- W fragments (this wave's CT x 16 output columns, all of Fin) -- as K4; bias -> LDS ---------------
   const int jw = NJ >= NW ? wave : wave % NJ;                  // this wave's column tiles: CT jw .. + CT - 1
   const int tt0 = NJ >= NW ? 0 : wave / NJ;                    // its first row tile
-  constexpr int NSW = K8_ABL_NOWLO ? 1 : NS;            // W images kept in registers
-  bf16x8 bw[CT][KS][NSW];
+  bf16x8 bw[CT][KS][NS];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int j = CT * jw + ct;                                // adjacent tiles: full 128-B lines per row
@@ -365,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       const float4_t w1 = *reinterpret_cast<const float4_t *>(wp + 4);
       const float w8[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
       if constexpr (F16) gwen::split_f16<8>(w8, kw, bw[ct][ks][0], bw[ct][ks][1]);
-      else gwen::split_images<8, NSW>(w8, bw[ct][ks]);
+      else gwen::split_images<8, NS>(w8, bw[ct][ks]);
     }
   }
   {
@@ -377,7 +279,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)       // every global load above is waited for here, not inside the pipeline
 #pragma unroll
-      for (int s_ = 0; s_ < NSW; ++s_) asm volatile("" : "+v"(bw[ct][ks][s_]));
+      for (int s_ = 0; s_ < NS; ++s_) asm volatile("" : "+v"(bw[ct][ks][s_]));
 
   // ---- F16: scale + cut of an aggregated row piece; the epilogue's un-scale -----------------------------------
   // eprev[p]: the biased exponent this lane's row of aggregate pass p was scaled by in the chunk before (a lane
@@ -552,7 +454,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   };
 
   // the same, one pass after the other with half a row's entries in flight (what the register budget at
-  // Fin = 256 leaves when nothing else of the step is interleaved: K8_ROLES)
+  // Fin = 256 leaves when nothing else of the step is interleaved: ROLES)
   auto aggregate_lean = [&](int sb, int ab, int eb) {
     const char *ent = lds + kOffEnt + eb * kEntBytes;
     const char *stg = lds + kOffStage + sb * kStageBytes + mi * 16;
@@ -658,15 +560,15 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
   // EARLYR: the row ids of the chunk a step issues are loaded (scalar loads) in the step BEFORE, behind its last DMA,
   // instead of in front of the step's own barrier -- the barrier's fence waits for every outstanding scalar load
   // (lgkmcnt), i.e. their whole latency stood in front of every barrier
-  constexpr bool EARLYR = K8_EARLYR && !DENSE && !ROLES;
+  constexpr bool EARLYR = !DENSE && !ROLES;
   constexpr int kLastDma = NQ - 1 < NU - 1 ? NQ - 1 : NU - 1;                   // region of a step's last DMA
-  constexpr int kEarlyU = NU == 8 && K8_EARLYR_U > kLastDma ? K8_EARLYR_U : (kLastDma + 1 < NU ? kLastDma + 1 : NU - 1);
+  constexpr int kEarlyU = NU == 8 && kEarlyRegion > kLastDma ? kEarlyRegion : (kLastDma + 1 < NU ? kLastDma + 1 : NU - 1);
   int32_t r[4 * NQ];
   // VOFFQ (4 chunks per tile): this lane's byte offset of its row in each DMA group is computed ONCE per tile (the row
   // select by lane quarter + multiply: ~5 vector instructions per DMA) and kept; the chunk's 256 bytes go into the scalar
   // base.  The matrix pipe and the vector ALU of a SIMD do not run side by side (tools/experiments/pipes/overlap.hip:
   // their times add), so every vector instruction taken out of the step is time
-  constexpr bool VOFFQ = K8_VOFFQ && EARLYR && NC == 4 && NQ == 4;     // (unions <= 128 rows: four DMA groups per wave)
+  constexpr bool VOFFQ = EARLYR && NC == 4 && NQ == 4;     // (unions <= 128 rows: four DMA groups per wave)
   u32x4 voffq = {0, 0, 0, 0};                          // (a vector, not an array: hipcc put the array in scratch)
   auto make_voffq = [&]() {
     gwen_static_for<(VOFFQ ? 4 : 0)>([&](auto qq) {
@@ -713,14 +615,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           for (int k = 0; k < 4; ++k) r[4 * q + k] = rp[4 * NW * q + k];
       }
       const float *bl = reinterpret_cast<const float *>(lds + kOffBias);
-#if K8_STAMP
-      uint64_t ts[5] = {0, 0, 0, 0, 0};
-#endif
-      K8_TS(0);
       wait_vmcnt(young);
-      K8_TS(1);
       __syncthreads();
-      K8_TS(2);
       int n_ops = 0;
       // ---- stores of tile i-1: a tile whose 64 rows all exist is stored region by region with every lane
       // active (exact instruction counts for the waits); the last tile of a member at once, guarded, drained
@@ -747,8 +643,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
           s_ok = r < N;
           srow = out + (int64_t)ms * mstride_o + (int64_t)r * ldo + (CT * jw * 16 + 4 * mh);
           if constexpr (F16) erow[tfin] = *reinterpret_cast<const int *>(side_src(tfin));   // (its last chunk's slot: read this step)
-          if (K8_ABL_STORE_LOCAL)     // TIMING ABLATION: every block rewrites its own 64 rows (cache-resident): no HBM writes
-            srow = out + (int64_t)(blockIdx.x * kRows + tfin * 16 + mi) * ldo + (CT * jw * 16 + 4 * mh);
         }
       };
       float4_t sbias[CT];
@@ -777,12 +671,12 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
       u32x4 lid4 = {0, 0, 0, 0};
       float4_t wa = {0.f, 0.f, 0.f, 0.f}, wb = wa, acc = wa;
       // (the matrix pipe and the vector ALU of a SIMD take turns -- pipes/overlap.hip -- so address arithmetic is step time)
-      constexpr bool PERM = K8_PERM && !DENSE && NSTG == 2 && NC % 2 == 0 && kUCap <= 256 && NW == 8 && KU == 128;   // (elsewhere the extra register spills)
+      constexpr bool PERM = !DENSE && NSTG == 2 && NC % 2 == 0 && kUCap <= 256 && NW == 8 && KU == 128;   // (elsewhere the extra register spills)
       const uint32_t lane16b = (uint32_t)(mi * 16);
       // SHIFT: stage k's vector work is issued in the region AFTER its LDS reads (the last stage's in the last region),
       // the two halves of a row's entries landing in two register buffers; without it (one buffer) a region's fma
       // chains wait for the reads issued at its own start: ~150-250 cycles of LDS latency in front of the region's MFMAs
-      constexpr bool SHIFT = K8_SHIFT && !DENSE && NSTAGE == NU && NU >= 4 && !(NS == 3 && NW == 16) &&   // (128-register waves: bf16x6 would spill)
+      constexpr bool SHIFT = !DENSE && NSTAGE == NU && NU >= 4 && !(NS == 3 && NW == 16) &&   // (128-register waves: bf16x6 would spill)
                              !(F16 && FIN == 256 && FOUT == 256);   // (f16x3 at 256 -> 256: the second row buffer does not fit the
                                                                     //  registers -- 10 spilled, reloaded from scratch in every step: 327 us
                                                                     //  against 268 without it; three-row buffers and reads issued at the
@@ -916,7 +810,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               }
             }
           }
-          if (K8_PRIO) __builtin_amdgcn_s_setprio(K8_PRIO);
           gwen_static_for<NU>([&](auto uu) {
             constexpr int u = decltype(uu)::value;
             constexpr int ti = u >> 1, k2 = u & 1, ks = 2 * c + k2;
@@ -934,17 +827,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               // the first unit of a tile starts from a ZERO C operand (an inline constant of the MFMA) instead of
               // re-zeroed accumulator registers: 32 moves per tile and wave less on the vector ALU
               const f32x4 cin = (c == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
-              if constexpr (K8_ABL_NOWLO) {
-                bf16x8 wt[NS];
-#pragma unroll
-                for (int s_ = 0; s_ < NS; ++s_) wt[s_] = bw[ct][ks][0];
-                d[ct][ti] = gwen::mma_split<8, NS>(wt, acur, cin);
-              } else {
-                d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, cin);
-              }
+              d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, cin);
             }
           });
-          if (K8_PRIO) __builtin_amdgcn_s_setprio(0);
         };
         // (with every row read of a half in flight instead of 4 at a time -- aggregate() -- the 256-channel kernel spills
         //  52 registers: 389 us against 252; the lean form spills 20 there: 292 us.  ROLES is not for 256 channels.)
@@ -1016,7 +901,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             for (int k = 0; k < 4; ++k) r[4 * q + k] = rpn[4 * NW * q + k];
         }
         if constexpr (SKEW && u == 2) store_target();
-        if constexpr (SKEW && K8_SBIAS && !F16) {           // a store's bias fragment is read one region ahead of it
+        if constexpr (SKEW && !F16) {           // a store's bias fragment is read one region ahead of it
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
             if ((ct == 0 ? sreg0 : sreg1) - 1 == u) sbias[ct] = *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh);
@@ -1031,9 +916,8 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
             for (int ct = 0; ct < CT; ++ct) {
               if ((ct == 0 ? sreg0 : sreg1) != u) continue;          // (wave-uniform: a scalar branch)
               float4_t o = finish4(d[ct][tfin], erow[tfin], (CT * jw + ct) * 16 + 4 * mh,
-                                   K8_SBIAS && !F16 ? sbias[ct] : *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
+                                   !F16 ? sbias[ct] : *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
               o = relu4(o, relu, floor_bits);
-              if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
               float4_t *dst = reinterpret_cast<float4_t *>(srow + ct * 16);
               if (s_whole) {                                 // every lane stores: exactly one instruction (the waits count)
                 if (nt) __builtin_nontemporal_store(o, dst);
@@ -1056,11 +940,10 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
                 float4_t o = finish4(d[ct][ti], erow[ti], (CT * jw + ct) * 16 + 4 * mh,
                                      *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
                 o = relu4(o, relu, floor_bits);
-                if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
-                if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
+                  if (nt) __builtin_nontemporal_store(o, reinterpret_cast<float4_t *>(orow + ct * 16));
                 else *reinterpret_cast<float4_t *>(orow + ct * 16) = o;
               }
-              n_ops += K8_ABL_NOSTORE ? 0 : CT;
+              n_ops += CT;
             }
           }
         }
@@ -1096,11 +979,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
               const f32x4 cin = (cu == 0 && k2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[ct][ti];
               if constexpr (F16) {
                 d[ct][ti] = gwen::mma_split_f16(bw[ct][ks], acur, cin);
-              } else if constexpr (K8_ABL_NOWLO) {
-                bf16x8 wt[NS];
-#pragma unroll
-                for (int s_ = 0; s_ < NS; ++s_) wt[s_] = bw[ct][ks][0];
-                d[ct][ti] = gwen::mma_split<8, NS>(wt, acur, cin);
               } else {
                 d[ct][ti] = gwen::mma_split<8, NS>(bw[ct][ks], acur, cin);
               }
@@ -1114,27 +992,9 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
 #pragma unroll
         for (int k = 0; k < CT * (NS == 2 ? 3 : 6); ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, WEAVE_VALU, 0);     // a few VALU instructions behind it
+          __builtin_amdgcn_sched_group_barrier(0x002, kWeaveValu, 0);     // a few VALU instructions behind it
         }
-#if K8_STAMP
-        if constexpr (u == NU / 2 - 1) { __builtin_amdgcn_sched_barrier(0); K8_TS(3); __builtin_amdgcn_sched_barrier(0); }
-        if constexpr (u == NU - 1) { __builtin_amdgcn_sched_barrier(0); K8_TS(4); __builtin_amdgcn_sched_barrier(0); }
-#endif
       });
-#if K8_STAMP
-      {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int rel = s - 2 * NC;                              // steps of tiles 2 .. : 32 of them
-        if (kStampBytes > 0 && blockIdx.x == K8_STAMP_BLOCK && rel >= 0 && rel < 32 && lane < 5) {
-          uint32_t tv = (uint32_t)ts[0];
-          tv = lane == 1 ? (uint32_t)ts[1] : tv;
-          tv = lane == 2 ? (uint32_t)ts[2] : tv;
-          tv = lane == 3 ? (uint32_t)ts[3] : tv;
-          tv = lane == 4 ? (uint32_t)ts[4] : tv;
-          reinterpret_cast<uint32_t *>(lds + kLds)[(wave * 32 + rel) * 8 + lane] = tv;
-        }
-      }
-#endif
       // what may stay in flight at the next wait: with two chunks of DMA in flight, everything this interval
       // issued (the DMA the next wait is for is older); with one, nothing (that DMA is among them)
       young = D == 3 ? n_ops + prev_ops : D == 2 ? n_ops : 0;
@@ -1165,7 +1025,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
         float4_t o = finish4(d[ct][rt], erow[rt], (CT * jw + ct) * 16 + 4 * mh,
                              *reinterpret_cast<const float4_t *>(bl + (CT * jw + ct) * 16 + 4 * mh));
         o = relu4(o, relu, floor_bits);
-        if (K8_ABL_NOSTORE) { asm volatile("" :: "v"(o)); continue; }
         if (r < N) *reinterpret_cast<float4_t *>(row + ct * 16) = o;
       }
     };
@@ -1207,11 +1066,6 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     store_tile(tile_of(ntl - 1));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the DMAs issued past the last tile
-#if K8_STAMP
-  __syncthreads();
-  if (kStampBytes > 0 && blockIdx.x == K8_STAMP_BLOCK)
-    for (int k = threadIdx.x; k < NW * 32 * 8; k += NW * 64) gwen_k8_stamp_buf[k] = reinterpret_cast<uint32_t *>(lds + kLds)[k];
-#endif
 }
 
 template <int FIN, int FOUT, int NW, int D, int KU, bool EARLY, bool DENSE = false, int NS = 2, bool F16 = false>
@@ -1232,7 +1086,7 @@ int launch(const int32_t *t_rows, const uint16_t *t_lid, const float *t_val, con
   // non-temporally: they then do not push the halo rows the tiles share out of the caches (64 channels x 16
   // members: 204 -> 191 us per layer in the 4-layer stack); a working set that fits stays on plain stores (the
   // next layer reads its input from the cache: 256 channels x 1 member 69.7 vs 74.3 us with nt)
-  const int nt = K8_NT >= 0 ? K8_NT : (members * N * (int64_t)(FIN + FOUT) * 4 > (int64_t(300) << 20) ? 1 : 0);
+  const int nt = members * N * (int64_t)(FIN + FOUT) * 4 > (int64_t(300) << 20) ? 1 : 0;
   k_wide<FIN, FOUT, NW, D, KU, EARLY, DENSE, NS, F16><<<(unsigned)blocks, NW * 64, 0, st>>>(
       t_rows, t_lid, t_val, x, W, bias, out, (int32_t)N, (int32_t)T, (int32_t)G, ldo, msx, mso, relu, (int32_t)ldx, nt);
   GWEN_LAUNCH_CHECK();
@@ -1286,7 +1140,7 @@ extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int c
 
 extern "C" int gwen_gcn_wide_preferred(int64_t N, int64_t members, int64_t Fin, int64_t Fout) {
   if (!gwen_gcn_wide_supported(Fin, Fout) || N <= 0 || members <= 0) return 0;
-  return Fin >= 128 || N * members >= K8_PREF_ROWS ? 1 : 0;
+  return Fin >= 128 || N * members >= kPrefRows ? 1 : 0;
 }
 
 extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_lid,
@@ -1350,13 +1204,12 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
 #define GWEN_ARGS t_rows, t_lid, t_val, x, W, bias, out, N, ldo, members, mstride_x, mstride_o, relu, st
 #define GWEN_W(FI, FO)                                                                                \
   if (Fin == FI && Fout == FO) {                                                                      \
-    constexpr int NWV = FI >= 256 ? (K8_ABL_NOWLO ? 16 : 8) : 16;                                     \
+    constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
     if constexpr (FI <= 128 || FO <= 128) {                                                           \
-      constexpr int D6 = K8_D6 > 0 ? K8_D6 : (FI == 64 ? 2 : 1);                                      \
-      constexpr int NW6 = (FI == 128 && ((K8_X6_128_NW8 >> (FO == 64 ? 0 : FO == 128 ? 1 : 2)) & 1)) ? 8 : NWV;   \
-      if (x6) return launch<FI, FO, NW6, D6, 128, true, false, 3>(GWEN_ARGS);                         \
+      constexpr int NW6 = FI == 128 ? x6_waves_128(FO) : NWV;                                         \
+      if (x6) return launch<FI, FO, NW6, dma_depth(FI), 128, true, false, 3>(GWEN_ARGS);              \
     }                                                                                                 \
-    constexpr int DV = K8_D > 0 ? K8_D : (FI == 64 ? 2 : 1);                                          \
+    constexpr int DV = dma_depth(FI);                                                                 \
     return small_union ? launch<FI, FO, NWV, DV, 128, true>(GWEN_ARGS)                                \
                        : launch<FI, FO, NWV, 1, 192, true>(GWEN_ARGS);                                \
   }

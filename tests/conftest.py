@@ -10,8 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if os.environ.get("GWEN_HIP_LIB"):
-        # an experimental / ablated variant build must never produce a green test run
+    if os.environ.get("GWEN_HIP_LIB") and os.environ.get("GWEN_ALLOW_VARIANT_TESTS") != "1":
+        # an experimental / ablated variant build must never produce a green test run by accident
+        # (tools/experiments/k8_variants.sh sets GWEN_ALLOW_VARIANT_TESTS=1 for its A/B parity runs)
         raise pytest.UsageError("GWEN_HIP_LIB is set: the tests run against the product library only (unset it)")
 
 
