@@ -328,7 +328,7 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30, members=1):
 
 def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's per-GPU load", order="auto"):
     """BASELINE c3's processor stack at c5's per-GPU member count: the regime where HBM bounds the path.
-    ``order``: "auto" = the library's default precision (fp32-class: K8's f16x3 from 128 channels, bf16x6 at 64),
+    ``order``: "auto" = the library's default precision (fp32-class: f16x3 in K8, bf16x6 in every other kernel),
     "auto_x6" = bf16x6 in every kernel, "auto_x3" = the bf16x3 split."""
     n, e = mesh.num_nodes, mesh.num_edges
     f, m, nl = f or args.hbm_channels, m or args.hbm_members, args.hbm_layers
@@ -357,7 +357,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
     avg = tot / cnt
     comp = compulsory_bytes(kind, n, e, fin, fout, m)
     ws_mib = 2 * 4 * m * n * f / 2 ** 20
-    ns = {"auto": "f16" if (kind == "wide" and fin >= 128) else 3, "auto_x6": 3, "auto_x3": 2}[order]
+    ns = {"auto": "f16" if kind == "wide" else 3, "auto_x6": 3, "auto_x3": 2}[order]
     tags = kernel_tags(kind, fin, fout, ns)
     launches_per_layer = 1
     if kind == "wide" and (fin, fout, ns) == (256, 256, 3):      # bf16x6 at 256 -> 256 = two 256 -> 128 launches
@@ -369,9 +369,8 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
                     f"nu={args.nu} N={n} E={e}; {ws_mib:.0f} MiB in+out per layer (Infinity Cache: 256 MiB)",
         "members": m, "channels": f, "layers": nl, "steps": steps,
         "contraction": {"f16": "f16x3: two power-of-two-scaled fp16 images per operand, three MFMA terms -- fp32-class, "
-                               "the library default from 128 input channels, ONE launch per layer",
-                        3: "bf16x6: three bf16 images per operand, six MFMA terms -- fp32-class"
-                           + (" (the library default at 64 channels)" if order == "auto" else " (precision \"bf16x6\")")
+                               "K8's split under the library default, ONE launch per layer",
+                        3: "bf16x6: three bf16 images per operand, six MFMA terms -- fp32-class (precision \"bf16x6\")"
                            + ("; 256 -> 256 as two 256 -> 128 launches" if launches_per_layer == 2 else ""),
                         2: "bf16x3 (precision \"3xbf16\"): two bf16 images, three MFMA terms, ~17 bits per product"}[ns],
         "launches_per_layer": launches_per_layer,
@@ -796,7 +795,7 @@ def main():
                    "contraction": {"auto": "the library default, fp32-class on each kernel's own split -- at this "
                                            "model's widths (<= 64) bf16x6: three bf16 images per operand, six MFMA "
                                            "terms, fp32 accumulation (see gpu_vs_oracle_rel_err; siblings: bf16x3, "
-                                           "exact_f32; from 128 channels K8 runs f16x3: hbm_leg)",
+                                           "exact_f32; K8 runs f16x3: hbm_leg)",
                                    "bf16x3": "bf16x3 split: two bf16 images per operand, three MFMA terms",
                                    "fused_exact": "fp32-input MFMA (exact fp32 products)",
                                    "unfused": "fp32-input MFMA in K3 (explicit orders contract in fp32)"}[args.order],
@@ -842,13 +841,16 @@ def main():
         line["hbm_leg"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto")
         line["hbm_leg"]["tier_3xbf16"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x3")
         line["hbm_leg"]["precision_bf16x6_two_launches"] = hbm_leg(gwen_amd, mesh, graph, args, dev, order="auto_x6")
-        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache (default there:
-        # bf16x6 on K8's two-chunk pipeline), the 3xbf16 tier beside it
+        # the same layer kernel at c2's 64 channels with enough members to leave the Infinity Cache (default: f16x3 on K8's
+        # two-chunk pipeline), the 3xbf16 tier and precision "bf16x6" beside it
         line["hbm_leg_64ch"] = hbm_leg(gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
                                        what="c2's width beyond the Infinity Cache", order="auto")
         line["hbm_leg_64ch"]["tier_3xbf16"] = hbm_leg(
             gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
             what="c2's width beyond the Infinity Cache", order="auto_x3")
+        line["hbm_leg_64ch"]["precision_bf16x6"] = hbm_leg(
+            gwen_amd, mesh, graph, args, dev, f=args.channels, m=args.hbm_members_narrow,
+            what="c2's width beyond the Infinity Cache", order="auto_x6")
 
     # ---- side measurement (outside the timed region, N = 1 only): the InteractionNet edge-MLP kernel
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline

@@ -72,13 +72,14 @@ CONTRACT_NAMES = {"3xbf16": CONTRACT_BF16X3, "bf16x3": CONTRACT_BF16X3, "fp32": 
 
 
 def dense_contract(code: int) -> int:
-    """"f16x3" on a layer means fp32-class on the kernel's own split: K8 has the scaled fp16 split (from 128 input
-    channels), every other kernel -- K3, K4, K5, K7 -- runs bf16x6 (csrc/forward.hip ``dense_contract``)."""
+    """"f16x3" on a layer means fp32-class on the kernel's own split: K8 has the scaled fp16 split at every
+    width, every other kernel -- K3, K4, K5, K7 -- runs bf16x6 (csrc/forward.hip ``dense_contract``)."""
     return CONTRACT_BF16X6 if code == CONTRACT_F16X3 else code
 
 
 def wide_contract(fin: int, fout: int, code: int) -> int:
-    """What K8 runs for a layer contract (csrc/forward.hip ``wide_contract``): f16x3 where it has it, else bf16x6."""
+    """What K8 runs for a layer contract (csrc/forward.hip ``wide_contract``): f16x3 where it has it (every supported
+    width pair today), else bf16x6."""
     if code == CONTRACT_F16X3 and not lib().gwen_gcn_wide_contract_supported(fin, fout, code):
         return CONTRACT_BF16X6
     return code

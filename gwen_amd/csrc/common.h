@@ -33,8 +33,8 @@ static inline int gwen_contract_of(const gwen_layer_desc &L) {
     return L.contract == GWEN_CONTRACT_BF16X6 || L.contract == GWEN_CONTRACT_F16X3 ? L.contract : GWEN_CONTRACT_BF16X3;
   return GWEN_CONTRACT_F32;
 }
-// GWEN_CONTRACT_F16X3 on a layer = "fp32-class, the kernel's own split": K8 has the scaled fp16 split from 128 input
-// channels; every other kernel (K3, K4, K5, K7, the backward, and K8 at 64 channels) runs its fp32-class split, bf16x6
+// GWEN_CONTRACT_F16X3 on a layer = "fp32-class, the kernel's own split": K8 has the scaled fp16 split; every
+// other kernel (K3, K4, K5, K7, the backward) runs its fp32-class split, bf16x6
 static inline int gwen_dense_contract(int c) { return c == GWEN_CONTRACT_F16X3 ? GWEN_CONTRACT_BF16X6 : c; }
 
 typedef float float4_t __attribute__((ext_vector_type(4)));

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void k_wide(
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int32_t T, int32_t G,
     int64_t ldo, int64_t mstride_x, int64_t mstride_o, int relu, int32_t ldx, int nt) {
   // ROLES (below): the two waves of a SIMD take the step's two halves in opposite order
-  constexpr bool ROLES = FIN == 64 && D == 1 && !DENSE;      // (measured faster there only; 256 channels: 267.7 vs 265.5 us)
+  constexpr bool ROLES = FIN == 64 && D == 1 && !DENSE && !F16;      // (measured faster there only; 256 channels: 267.7 vs 265.5 us)
   constexpr int NSTG = D + 1;                           // stage buffers
   constexpr int kStageBytes = KU * kFC * 4;
   constexpr int NC = FIN / kFC;                         // chunks per tile
@@ -1131,7 +1131,7 @@ extern "C" int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout) {
 extern "C" int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract) {
   if (!gwen_gcn_wide_supported(Fin, Fout)) return 0;
   if (contract == GWEN_CONTRACT_BF16X3) return 1;
-  if (contract == GWEN_CONTRACT_F16X3) return Fin >= 128 ? 1 : 0;     // (64 channels: bf16x6 has its own two-chunk pipeline)
+  if (contract == GWEN_CONTRACT_F16X3) return 1;
   // bf16x6 at 256 -> 256: three images of W are 192 of the 256 registers a wave has there (hipcc spills 85-91 of
   // them: 141-157 us per pass on one member against K4's 127, measured); 256 -> 64 / 128 hold half / a quarter of
   // the columns per wave and fit, so 256 -> 256 runs as two 256 -> 128 launches (gwen_gcn_wide_layer_f32).
@@ -1179,9 +1179,10 @@ extern "C" int gwen_gcn_wide_layer_f32(const int32_t *t_rows, const uint16_t *t_
 #define GWEN_H(FI, FO)                                                                                \
   if (Fin == FI && Fout == FO) {                                                                      \
     constexpr int NWV = FI >= 256 ? 8 : 16;                                                           \
-    return small_union ? launch<FI, FO, NWV, 1, 128, true, false, 2, true>(GWEN_ARGS)                 \
+    return small_union ? launch<FI, FO, NWV, dma_depth(FI), 128, true, false, 2, true>(GWEN_ARGS)     \
                        : launch<FI, FO, NWV, 1, 192, true, false, 2, true>(GWEN_ARGS);                \
   }
+    GWEN_H(64, 64); GWEN_H(64, 128); GWEN_H(64, 256);
     GWEN_H(128, 64); GWEN_H(128, 128); GWEN_H(128, 256);
     GWEN_H(256, 64); GWEN_H(256, 128); GWEN_H(256, 256);
 #undef GWEN_H

@@ -16,7 +16,7 @@ from . import _lib
 from .graph import GraphCSR, _ptr, _stream
 
 # order string -> (GWEN_ORDER_*, GWEN_CONTRACT_* of an AUTO / FUSED layer).  "auto" is the default precision,
-# fp32-class on the kernel's own split ("f16x3": K8 from 128 input channels on two scaled fp16 images, every other
+# fp32-class on the kernel's own split ("f16x3": K8 on two scaled fp16 images, every other
 # kernel on bf16x6); "auto_x6" / "fused" are bf16x6 in every kernel, "auto_x3" / "fused_x3" the faster bf16x3 split; the
 # explicit two-launch orders and "fused_exact" use the fp32-input MFMA whatever the second entry says.
 _ORDERS = {"auto": (_lib.ORDER_AUTO, _lib.CONTRACT_F16X3), "auto_x6": (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X6),

@@ -81,7 +81,7 @@ class GCNConv(nn.Module):
     def precision(self) -> str:
         """"f16x3" (default): fp32-class contractions (<= 2e-6 per layer against fp64; the reference's `lin` is an fp32
         GEMM, models_gnn.py:118-130) on each kernel's own split -- the tile-staged wide layer K8 cuts both operands into
-        two power-of-two-scaled fp16 images from 128 input channels (three MFMA terms, one launch at 256 -> 256), every
+        two power-of-two-scaled fp16 images (three MFMA terms, one launch at 256 -> 256), every
         other kernel into three bf16 images (six terms); "bf16x6": three bf16 images in every kernel (K8 at 256 -> 256
         then runs two launches); "3xbf16": the faster two-image split (~17 bits per product, 7e-6 on the model; meets the 1e-4 contract);
         "fp32": the fp32-input MFMA (exact fp32 products, bit-identical to a k-ordered fmaf chain).  The same

@@ -36,7 +36,7 @@ AUTO_ORDERS = ("auto", "auto_x6", "auto_x3")
 
 def contract_of_order(order: str) -> str:
     """Contraction of a layer run under ``order``: "auto" -> "f16x3" (the default: fp32-class on the kernel's own
-    split -- K8 from 128 input channels on two scaled fp16 images, every other kernel on bf16x6), "auto_x6" /
+    split -- K8 on two scaled fp16 images, every other kernel on bf16x6), "auto_x6" /
     "fused" -> "bf16x6" in every kernel, "auto_x3" / "fused_x3" -> "3xbf16", every other (explicit) order -> "fp32"."""
     if order == "auto":
         return "f16x3"
@@ -207,8 +207,8 @@ def wide_preferred(graph: GraphCSR, x: Tensor, fin: int, fout: int, contract: st
 def wide_layer(graph: GraphCSR, x: Tensor, weight: Tensor, bias: Optional[Tensor] = None,
                relu: bool = False, contract: str = "f16x3") -> Tensor:
     """K8: act((A~ x) W^T + b), tile-staged through LDS (widths in {64,128,256}, graphs that tile:
-    ``graph.tiles()``).  ``contract``: "f16x3" (the library default: fp32-class on two scaled fp16 images from 128
-    input channels, ONE launch at every width; at 64 channels it is bf16x6), "bf16x6" (graphs whose tile unions stay
+    ``graph.tiles()``).  ``contract``: "f16x3" (the library default: fp32-class on two scaled fp16 images, ONE launch
+    at every width), "bf16x6" (graphs whose tile unions stay
     within 128 rows; 256 -> 256 as two 256 -> 128 launches) or "3xbf16" -- the bf16 splits term for term K4's
     arithmetic."""
     _require(x, "x")

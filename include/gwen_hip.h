@@ -146,10 +146,10 @@ int gwen_gcn_propagate_f32(const int32_t *rowptr, const int32_t *col, const floa
  *                             (<= 2e-6 on the 6-layer model) at 6/16 of the fp32 MFMA's cost;
  *   GWEN_CONTRACT_F16X3  (3)  two fp16 images per operand, both operands scaled by exact powers of two (W per output
  *                             column, the rows per 64-feature chunk) so that fp16's range holds them: operands kept to
- *                             2^-24, 3 MFMAs per k-step -- fp32-class at bf16x3's cost.  K8 has it from 128 input
- *                             channels (gwen_gcn_wide_layer_f32).  On a layer of the stack launcher
+ *                             2^-24, 3 MFMAs per k-step -- fp32-class at bf16x3's cost.  K8 has it at every
+ *                             width (gwen_gcn_wide_layer_f32).  On a layer of the stack launcher
  *                             (gwen_layer_desc.contract) it means "fp32-class on the kernel's own split": K8 runs
- *                             f16x3, K3 / K4 / K5 / K7 and K8 at 64 channels run bf16x6 -- the host API's default.
+ *                             f16x3, K3 / K4 / K5 / K7 run bf16x6 -- the host API's default.
  * ------------------------------------------------------------------------------------------- */
 #define GWEN_CONTRACT_BF16X3 0
 #define GWEN_CONTRACT_F32 1
@@ -231,8 +231,8 @@ int gwen_cluster_rows64_host(const int32_t *rowptr, const int32_t *col, int64_t 
 int gwen_gcn_wide_supported(int64_t Fin, int64_t Fout);
 /* contract: GWEN_CONTRACT_BF16X3 or GWEN_CONTRACT_BF16X6 for every supported width pair (bf16x6 needs tile unions
  * within 128 rows; at 256 -> 256 it runs as two 256 -> 128 launches: three images of W for all 256 output columns
- * exceed the registers of the 8 waves that hold them); GWEN_CONTRACT_F16X3 for Fin in {128, 256}: one launch at every
- * width, unions up to GWEN_TILE_UNION rows. */
+ * exceed the registers of the 8 waves that hold them); GWEN_CONTRACT_F16X3: one launch at every width pair, unions up to
+ * GWEN_TILE_UNION rows. */
 int gwen_gcn_wide_contract_supported(int64_t Fin, int64_t Fout, int contract);
 /* 1 when an AUTO layer of these widths over N rows x members is issued as K8 rather than K4 (given a graph
  * that tiles): every supported width pair with Fin >= 128 (measured 1.15x - 1.6x K4), and Fin = 64 once the

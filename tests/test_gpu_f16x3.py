@@ -39,7 +39,8 @@ def _per_row(got, ref):
     return float((diff / scale).max())
 
 
-@pytest.mark.parametrize("fin,fout", [(128, 64), (128, 128), (128, 256), (256, 64), (256, 128), (256, 256)])
+@pytest.mark.parametrize("fin,fout", [(64, 64), (64, 128), (64, 256), (128, 64), (128, 128), (128, 256),
+                                      (256, 64), (256, 128), (256, 256)])
 @pytest.mark.parametrize("nu,reorder", [(4, "morton"), (13, "morton"), (13, "hilbert")])
 def test_f16x3_vs_oracle_every_width(ga, cref, fin, fout, nu, reorder):
     """morton at nu = 13 has unions above 128 rows (the 192-slot form -- what bf16x6 refuses), hilbert stays below
@@ -93,7 +94,8 @@ def _scaling_inputs(n, fin, fout, case, gen):
         x = x * s.repeat_interleave(64, 1)
     elif case == "chunk_steps":         # a chunk 2^40 below / above its neighbours (beyond the 2^16 back-off)
         s = torch.ones(n, fin // 64)
-        s[::2, 1] = 2.0 ** -40
+        if fin > 64:
+            s[::2, 1] = 2.0 ** -40
         s[1::2, -1] = 2.0 ** 40
         x = x * s.repeat_interleave(64, 1)
         b = torch.zeros(fout)
@@ -119,7 +121,8 @@ def _scaling_inputs(n, fin, fout, case, gen):
 
 @pytest.mark.parametrize("case", ["row_scales", "chunk_scales", "chunk_steps", "zero_chunks", "column_scales",
                                   "wide_range_in_row", "near_fp32_limits", "tiny"])
-@pytest.mark.parametrize("fin,fout,reorder", [(256, 256, "hilbert"), (256, 64, "morton"), (128, 128, "hilbert")])
+@pytest.mark.parametrize("fin,fout,reorder", [(256, 256, "hilbert"), (256, 64, "morton"), (128, 128, "hilbert"),
+                                              (64, 64, "hilbert"), (64, 128, "morton")])
 def test_f16x3_scaling_cases(ga, cref, case, fin, fout, reorder):
     from gwen_amd import ops
     m, ei, g = _mesh_graph(ga, 13, reorder)
