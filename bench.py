@@ -113,6 +113,8 @@ def parse():
     p.add_argument("--edge-mlp-members", type=int, default=8,
                    help="members of the batched edge-MLP side measurement (0: skip -- the PMC passes do, so that a "
                         "kernel name averages over one launch shape)")
+    p.add_argument("--edge-mlp-skip-single", action="store_true",
+                   help="only the batched edge-MLP side measurement (the PMC pass of the 8-member launch shape)")
     p.add_argument("--no-hbm-leg", action="store_true")
     p.add_argument("--no-exact", action="store_true")
     p.add_argument("--hbm-members", type=int, default=4)
@@ -242,7 +244,7 @@ def pmc_traffic(tag_prefixes):
     for k_, v in tf.items():
         for t in tag_prefixes:
             pre, suf = t if isinstance(t, tuple) else (t, "")
-            if k_.startswith(pre) and k_.endswith(suf):
+            if k_.startswith(pre) and k_.endswith(suf) and ("@" in suf or "@" not in k_):
                 return v["hbm_bytes_per_launch"]
     return None
 
@@ -322,7 +324,8 @@ def edge_mlp_side_measurement(mesh, f, dev, launches=30, members=1):
             "roofline": {"bound": "hbm" if f <= 64 else "mfma", "compulsory_bytes": b_comp,
                          "achieved_GBs": round(b_comp / t / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                          "frac": round(b_comp / t / 1e9 / HBM_PEAK_GBS, 4),
-                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([f"k_mlp2r<{f},", f"k_mlp2<{f},"]) if members == 1 else None,
+                         "l2_path_bytes": b_l2, "traffic": pmc_traffic([(f"k_mlp2r<{f},", "" if members == 1 else f"@{members}members"),
+                                                 (f"k_mlp2<{f},", "" if members == 1 else f"@{members}members")]),
                          "bf16_tflops_issued": round(12 * f * f * e / t / 1e12, 1)}}
 
 
@@ -832,6 +835,9 @@ def main():
         line["exact_f32"] = sibling("fused_exact", "fp32-input MFMA (v_mfma_f32_16x16x4_f32), order fused_exact")
         line["bf16x3"] = sibling("bf16x3", "two bf16 images per operand, three MFMA terms (precision \"3xbf16\"): "
                                            "7e-6 relative on this model, inside the 1e-4 contract")
+        # comparable round over round: rounds 1-2 quoted `value` on this tier (BENCH_r02: 41.46 G); since round 3 `value`
+        # is the fp32-class default, ~5 % slower on this model
+        line["value_tier_3xbf16"] = line["bf16x3"]["edges_per_s"]
 
     # ---- HBM-bound leg ----------------------------------------------------------------------------------
     if single and not args.no_hbm_leg:
@@ -856,7 +862,8 @@ def main():
     # K6 on the same mesh at the same width -- the block BASELINE.json's north_star names; the headline
     # value above stays the reference's own layer (GCNConv) -------------------------------------------
     if single and not args.no_edge_mlp and h in (32, 64, 128, 256):
-        line["edge_mlp_block"] = edge_mlp_side_measurement(mesh, h, dev)
+        if not args.edge_mlp_skip_single:
+            line["edge_mlp_block"] = edge_mlp_side_measurement(mesh, h, dev)
         # ... and on 8 members at once (2.9 GB of compulsory traffic at 64 channels: nothing stays in a cache)
         if args.edge_mlp_members > 1:
             line[f"edge_mlp_block_{args.edge_mlp_members}_members"] = edge_mlp_side_measurement(

@@ -2,18 +2,19 @@
 (default 4 "processor steps"), M members (default 1; 4 = config c5's per-GPU load).  One JSON line: us per
 sequence and per pass, edges/s per pass, the roofline of one pass (compulsory bytes / time / 8 TB/s, and
 SURVEY 8(d)'s L2-path bytes beside it), and the relative error of one member against the plain-C oracle
-(oracle/gcn_ref.c, fp64) chained on the host.     python tools/c3_bench.py [F] [S] [M] [--precision bf16x6|3xbf16]
-(default: the library default bf16x6 -- K4 at 256 channels; 3xbf16 -- K8, the tile-staged kernel)"""
+(oracle/gcn_ref.c, fp64) chained on the host.     python tools/c3_bench.py [F] [S] [M] [--precision f16x3|bf16x6|3xbf16]
+(default: the library default f16x3 -- K8 on the scaled fp16 split, one launch per layer; bf16x6 -- K8 as two
+256 -> 128 launches at 256 channels; 3xbf16 -- K8 on the 17-bit tier)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch, gwen_amd
-PREC = "bf16x6"
+PREC = "f16x3"
 if "--precision" in sys.argv:
     i = sys.argv.index("--precision")
     PREC = sys.argv[i + 1]
     del sys.argv[i:i + 2]
-ORDER = {"bf16x6": "auto", "3xbf16": "auto_x3"}[PREC]
+ORDER = {"f16x3": "auto", "bf16x6": "auto_x6", "3xbf16": "auto_x3"}[PREC]
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 1

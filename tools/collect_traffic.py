@@ -39,6 +39,16 @@ def main():
         out["kernels"][k] = {"FETCH_SIZE_KiB_raw": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                              "launches_sampled": [nf.get(k, 0), nw.get(k, 0)],
                              "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    # the 8-member edge-MLP block (its own pair of passes: pmc8_fetch / pmc8_write), keyed with an @8members suffix
+    fetch8, nf8 = per_kernel(f"{src}/pmc8_fetch/**/*counter_collection.csv", "FETCH_SIZE")
+    write8, nw8 = per_kernel(f"{src}/pmc8_write/**/*counter_collection.csv", "WRITE_SIZE")
+    for k in sorted(set(fetch8) & set(write8)):
+        if not k.startswith("k_mlp2"):
+            continue
+        f, w = fetch8[k], write8[k]
+        out["kernels"][k + "@8members"] = {"FETCH_SIZE_KiB_raw": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                                           "launches_sampled": [nf8.get(k, 0), nw8.get(k, 0)],
+                                           "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -5,7 +5,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-P=${2:-3xbf16}      # contraction of the c3 legs: 3xbf16 = K8 (the tile-staged kernel), bf16x6 = the library default (K4 at 256)
+P=${2:-f16x3}       # precision of the c3 legs: f16x3 = the library default (K8, one launch per layer), 3xbf16 = the 17-bit tier
 for m in 1 4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_m$m -- python3 $R/tools/c3_bench.py 256 4 $m --no-parity --precision $P > $out/c3_m$m.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/c3_m${m}_fetch -- python3 $R/tools/c3_bench.py 256 4 $m --no-parity --precision $P > /dev/null 2>&1
@@ -14,6 +14,8 @@ done
 python3 $R/tools/c3_bench.py 256 4 1 --precision $P > $out/c3_m1_parity.json 2>/dev/null
 python3 $R/tools/c3_bench.py 256 4 4 --precision $P > $out/c3_m4_parity.json 2>/dev/null
 python3 $R/tools/c3_bench.py 256 4 1 --precision bf16x6 > $out/c3_m1_bf16x6.json 2>/dev/null
+python3 $R/tools/c3_bench.py 256 4 1 --precision 3xbf16 > $out/c3_m1_3xbf16.json 2>/dev/null
+python3 $R/tools/c3_bench.py 256 4 4 --precision 3xbf16 > $out/c3_m4_3xbf16.json 2>/dev/null
 for h in 64 256; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/fc_$h -- python3 $R/tools/forecaster_bench.py 8 $h 4 4 > $out/fc_$h.log 2>&1
 done
