@@ -313,3 +313,40 @@ def test_cluster_rows64_host_grows_compact_patches():
     assert L.gwen_cluster_rows64_host(rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n, n + 1,
                                       perm.ctypes.data_as(C.c_void_p)) != 0
     assert L.gwen_cluster_rows64_host(None, None, 0, 0, None) == 0
+
+
+def test_precision_names_and_what_each_kernel_runs():
+    """The library default is "f16x3": fp32-class on the kernel's own split (K8: two scaled fp16 images; every other
+    kernel: bf16x6).  The names map to layer orders and contraction codes without a GPU (host logic only)."""
+    import gwen_amd
+    from gwen_amd import _lib, ops
+    from gwen_amd.forward import _ORDERS
+    conv = gwen_amd.GCNConv(64, 64)
+    assert conv.order == "auto" and conv.precision == "f16x3"
+    for name, order in (("f16x3", "auto"), ("bf16x6", "auto_x6"), ("3xbf16", "auto_x3")):
+        conv.precision = name
+        assert conv.order == order and conv.precision == name
+        assert ops.contract_of_order(order) == name and order in ops.AUTO_ORDERS
+    conv.precision = "fp32"
+    assert conv.order == "fused_exact" and conv.precision == "fp32"
+    with pytest.raises(ValueError):
+        conv.precision = "bf16"
+    assert _ORDERS["auto"] == (_lib.ORDER_AUTO, _lib.CONTRACT_F16X3)
+    assert _ORDERS["auto_x6"] == (_lib.ORDER_AUTO, _lib.CONTRACT_BF16X6)
+    assert _ORDERS["fused"] == (_lib.ORDER_FUSED, _lib.CONTRACT_BF16X6)
+    # K3 / K4 / K5 / K7 run bf16x6 for an f16x3 layer; the other codes pass through
+    assert _lib.dense_contract(_lib.CONTRACT_F16X3) == _lib.CONTRACT_BF16X6
+    for code in (_lib.CONTRACT_BF16X3, _lib.CONTRACT_F32, _lib.CONTRACT_BF16X6):
+        assert _lib.dense_contract(code) == code
+    assert ops._dense_code("f16x3") == _lib.CONTRACT_BF16X6 and ops._contract_code("f16x3") == _lib.CONTRACT_F16X3
+    # K8 has f16x3 at every width pair it supports (a library query: no GPU work)
+    lib = _lib.lib()
+    for fin in (64, 128, 256):
+        for fout in (64, 128, 256):
+            assert lib.gwen_gcn_wide_contract_supported(fin, fout, _lib.CONTRACT_F16X3) == 1
+            assert _lib.wide_contract(fin, fout, _lib.CONTRACT_F16X3) == _lib.CONTRACT_F16X3
+    assert lib.gwen_gcn_wide_contract_supported(96, 64, _lib.CONTRACT_F16X3) == 0
+    model = gwen_amd.GNNModel(gwen_amd.GNNConfig(10, 10, 16, 16, 32))
+    assert {c.precision for c in model.modules() if isinstance(c, gwen_amd.GCNConv)} == {"f16x3"}
+    model.set_precision("3xbf16")
+    assert {c.order for c in model.modules() if isinstance(c, gwen_amd.GCNConv)} == {"auto_x3"}
