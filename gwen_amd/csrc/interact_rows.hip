@@ -35,23 +35,9 @@
 // (the first contraction accumulates onto them), so the pass body exists twice with the two sets swapped.
 #include "common.h"
 #include "rows_common.h"
-#ifndef K6R_RT
-#define K6R_RT 1      // 16-row tiles per wave (see RCfg)
-#endif
-#ifndef ABL
-#define ABL 0     // timing ablations (tools/experiments/abl_k6r.sh); results are wrong by construction for ABL != 0
-#endif
-#ifdef GWEN_K6R_STAMPS   // diagnostic build only (tools/experiments/k6r_stamps.py): s_memtime per phase and wave
-__device__ uint64_t *g_k6r_stamps = nullptr;
-#define STAMP_DECL uint64_t tacc[8] = {}; uint64_t tprev = __builtin_amdgcn_s_memtime()
-#define STAMP(k) do { const uint64_t tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; } while (0)
-#define STAMP_FLUSH do { if ((threadIdx.x & 63) == 0 && g_k6r_stamps) for (int k = 0; k < 8; ++k) \
-    g_k6r_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = tacc[k]; } while (0)   /* waves 4-7 stay 0 at RT = 2 */
-#else
-#define STAMP_DECL
-#define STAMP(k)
-#define STAMP_FLUSH
-#endif
+// (the lab version of this file -- timing ablations -DABL=1..7, per-phase s_memtime stamps -DGWEN_K6R_STAMPS, two row
+//  tiles per wave -DK6R_RT=2 -- is tools/experiments/interact_rows_lab.patch; DESIGN.md section 4 / 7.3 has their numbers)
+constexpr int K6R_RT = 1;      // 16-row tiles per wave (see RCfg)
 
 namespace {
 
@@ -272,7 +258,6 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
   using V = Vis<F, RT, M1, M2, RES>;
 
   bool last_pass = false;
-  STAMP_DECL;
   // One pass.  E: this pass's A rows (later the residual).  H: pre-loaded with the G2 rows (or zero) -- the first
   // contraction accumulates onto it, the activation turns it into the hidden layer, the second contraction
   // consumes it and the NEXT pass's A rows move in.  rc: G1 rows, then the second contraction's accumulators.
@@ -335,11 +320,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
         if constexpr (si == 0) wait_vm<0>();
         else if constexpr (si == 1) wait_vm<C::DPW + V::of(0)>();
         else wait_vm<V::of(si - 2) + C::DPW + V::of(si - 1)>();
-        STAMP(si == 0 ? 0 : 1);
-#if ABL != 2
         __syncthreads();                                             // ... for every wave; slot - 1 is free
-#endif
-        STAMP(2);
       }
       if constexpr (si == C::KS) {
         // the activation: hidden = act(acc + G1 rows + b1), in place; the second accumulators start at b2.
@@ -359,11 +340,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
       }
       if constexpr (!C::RESIDENT) {
         const int into = slot >= 1 ? slot - 1 : C::NSLOT - 1;        // (slot + 2) % 3
-#if ABL != 3 && ABL != 4
         dma((si + 2) % (2 * C::KS), into);
-#else
-        (void)into;
-#endif
       }
       // ---- this step's B operands, from registers ----------------------------------------------------------
       bf16x8 bh[RT], bo[RT];
@@ -423,11 +400,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
         bf16x8 wh[C::JG], wl[C::JG];
 #pragma unroll
         for (int d = 0; d < C::JG; ++d) {
-#if ABL == 1 || ABL == 4
-          const int jr = 0;
-#else
           const int jr = jo + d;
-#endif
           wh[d] = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2) * 1024);
           wl[d] = *reinterpret_cast<const bf16x8 *>(wb + (jr * 2 + 1) * 1024);
         }
@@ -445,7 +418,6 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
             }
       }
       slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
-      STAMP(si == C::KS ? 4 : 3);
     });
 
     // ---- out = res + y stored from registers; E's registers then take the next pass's G2 rows (its first
@@ -494,11 +466,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const float4_t v = *reinterpret_cast<const float4_t *>(yown + (4 * k + gs) * C::PY + 4 * ps);
-#if ABL == 5 || ABL == 7
-              asm volatile("" :: "v"(v));
-#else
               if (wrow + 4 * k + gs < n_rows) *reinterpret_cast<float4_t *>(po + (int64_t)(4 * k) * F + 64 * c) = v;
-#endif
               asm volatile("" ::: "memory");
             }
           }
@@ -507,13 +475,12 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
       const char *p2 = reinterpret_cast<const char *>(G2) + ((uint32_t)i2n[rt] * ldb2 + 16u * gs);
 #pragma unroll
       for (int j = 0; j < C::NJ; ++j) {
-        if constexpr (M2 != kNone && ABL != 6 && ABL != 7)
+        if constexpr (M2 != kNone)
           E[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(p2 + 64 * j);
         else
           E[rt * C::NJ + j] = float4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
-    STAMP(5);
     // ---- the messages of each target row, summed in stored order, 64 columns at a time -------------------------
     if constexpr (SEG) {
       const int q = t % C::Q;
@@ -526,7 +493,6 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
           for (int j = 0; j < C::JC; ++j)
             *reinterpret_cast<float4_t *>(ytile + prow(rt) * C::PY + 16 * j + 4 * g) = rc[rt * C::NJ + c * C::JC + j];
         __syncthreads();
-        STAMP(6);
         int32_t s = seg_s, en = seg_e;
         for (int32_t r = cur.r0 + t / C::Q; r < cur.r1; r += C::SLOTS) {
           if (r != cur.r0 + t / C::Q) {                              // a pass with more target rows than slots
@@ -550,9 +516,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
             *reinterpret_cast<float4_t *>(dst) = float4_t{0.f, 0.f, 0.f, 0.f};     // no in-edges
           }
         }
-        STAMP(7);
         __syncthreads();
-        STAMP(5);
       });
     }
 #pragma unroll
@@ -578,7 +542,6 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
     if (last_pass) break;
   }
   if constexpr (!C::RESIDENT) wait_vm<0>();                          // the DMAs issued past the last chunk used
-  STAMP_FLUSH;
 }
 
 template <int F, int M1, int M2>
@@ -619,12 +582,6 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }
-
-#ifdef GWEN_K6R_STAMPS
-}
-extern "C" int gwen_k6r_set_stamps(uint64_t *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k6r_stamps), &p, sizeof(p)); }
-namespace {
-#endif
 
 }  // namespace
 
