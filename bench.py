@@ -103,6 +103,11 @@ def parse():
                    help="replay a captured hipGraph per step instead of issuing the launches from the C "
                         "launcher (measured slower here: one graph launch costs more than 6 direct ones)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="do not run the two rocprofv3 --pmc child passes at the start (roofline.traffic then comes from "
+                        "the committed passes, profiles/traffic.json)")
+    p.add_argument("--live-traffic-limit", type=float, default=150.0, help="time limit of each PMC child pass, seconds")
+    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--allow-variant", action="store_true",
                    help="run although GWEN_HIP_LIB points at an experimental build of the library (the line then "
                         "carries library.variant = true; such a line is not a measurement of the product)")
@@ -234,13 +239,145 @@ def prewarm(fn, seconds=None):
         torch.cuda.synchronize()
 
 
-def pmc_traffic(tag_prefixes):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/traffic.json, written
-    by tools/collect_traffic.py from two separate rocprofv3 --pmc runs of this command)."""
+# ---- HBM traffic from the PMC counters -------------------------------------------------------------------------------
+# Collected LIVE at the start of a default run: two short child processes of this file under `rocprofv3 --pmc`
+# (FETCH_SIZE, then WRITE_SIZE -- they can not share a pass on gfx950 -- and never together with a trace domain), each
+# launching every kernel the line quotes a few times (--pmc-child), BEFORE this process touches the GPU.  The
+# corrections are the guide's (MI355X_MICROARCH.md): FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream
+# (x 2), both counters are in KiB.  If rocprofv3 is missing, fails or runs out of its time limit, the committed passes of
+# the same command (profiles/traffic.json, tools/profile_bench.sh + tools/collect_traffic.py) are used and the line says so.
+LIVE_TRAFFIC = None            # {"kernels": {name: {...}}} once collected
+TRAFFIC_SOURCE = "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                 "gfx950 corrections applied)"
+KERNEL_RE = r"(k_(?:layer|chain|gather|propagate|linear_split|linear|wide|mlp2r|mlp2)<[^>]*>)"
+
+
+def _pmc_pass(counter, child_argv, tmp, limit_s):
+    """One `rocprofv3 --pmc <counter>` child pass; returns ({kernel: [values in dispatch order]}, None) or (None, why)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out_dir = os.path.join(tmp, counter)
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+           os.path.abspath(__file__)] + child_argv
+    env = {**os.environ, "TMPDIR": tmp}
     try:
-        tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
-    except (OSError, KeyError, ValueError):
-        return None
+        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=limit_s)
+    except (subprocess.TimeoutExpired, OSError) as exc:
+        return None, f"{type(exc).__name__}"
+    if r.returncode != 0:
+        return None, f"exit code {r.returncode}"
+    rows = []
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row.get("Counter_Name") == counter:
+                m = re.search(KERNEL_RE, row["Kernel_Name"])
+                if m:
+                    rows.append((int(row.get("Dispatch_Id", 0)), m.group(1), float(row["Counter_Value"])))
+    rows.sort()
+    per = {}
+    for _, name, val in rows:
+        per.setdefault(name, []).append(val)
+    return (per, None) if per else (None, "no counter rows")
+
+
+def collect_live_traffic(args):
+    """Fills LIVE_TRAFFIC / TRAFFIC_SOURCE (see above).  Runs before anything in this process initialises the GPU."""
+    global LIVE_TRAFFIC, TRAFFIC_SOURCE
+    import tempfile
+    t0 = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="gwen_pmc_", dir="/tmp")
+    child = ["--pmc-child", "--nu", str(args.nu), "--channels", str(args.channels), "--hidden", str(args.hidden),
+             "--reorder", args.reorder, "--hbm-members", str(args.hbm_members), "--hbm-channels", str(args.hbm_channels),
+             "--hbm-members-narrow", str(args.hbm_members_narrow), "--hbm-layers", str(args.hbm_layers),
+             "--edge-mlp-members", str(args.edge_mlp_members)]
+    fetch, why = _pmc_pass("FETCH_SIZE", child, tmp, args.live_traffic_limit)
+    write, why2 = (None, why) if fetch is None else _pmc_pass("WRITE_SIZE", child, tmp, args.live_traffic_limit)
+    try:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    except OSError:
+        pass
+    if fetch is None or write is None:
+        TRAFFIC_SOURCE += f"; the live passes of this run failed ({why or why2})"
+        return
+    n1 = 3                          # the child launches the edge block 3 times on one member, then on the batch (below)
+    kernels = {}
+    for name in sorted(set(fetch) & set(write)):
+        f_, w_ = fetch[name], write[name]
+        groups = [("", f_, w_)]
+        if name.startswith("k_mlp2") and len(f_) > n1 and len(w_) > n1 and args.edge_mlp_members > 1:
+            groups = [("", f_[:n1], w_[:n1]), (f"@{args.edge_mlp_members}members", f_[n1:], w_[n1:])]
+        for suffix, fv, wv in groups:
+            fm, wm = sum(fv) / len(fv), sum(wv) / len(wv)
+            kernels[name + suffix] = {"FETCH_SIZE_KiB_raw": round(fm, 1), "WRITE_SIZE_KiB": round(wm, 1),
+                                      "launches_sampled": [len(fv), len(wv)],
+                                      "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}
+    LIVE_TRAFFIC = {"kernels": kernels}
+    TRAFFIC_SOURCE = (f"LIVE: two rocprofv3 --pmc child passes of this run (FETCH_SIZE x 2 per the guide's gfx950 note, "
+                      f"WRITE_SIZE; {time.perf_counter() - t0:.0f} s, before the timed region and before this process "
+                      f"touched the GPU)")
+
+
+def pmc_child(args):
+    """--pmc-child: launch every kernel the line quotes a few times and exit (the process rocprofv3 --pmc watches)."""
+    import gwen_amd
+    from gwen_amd import ops
+    from gwen_amd.interaction import InteractionNet, interaction_graph, mlp2
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    mesh = gwen_amd.geodesic_mesh(args.nu, reorder=None if args.reorder == "none" else args.reorder)
+    n, c, h = mesh.num_nodes, args.channels, args.hidden
+    torch.manual_seed(23)
+    model = gwen_amd.GNNModel(gwen_amd.GNNConfig(n, n, c, c, h)).to(dev).eval()
+    ei = torch.from_numpy(mesh.edge_index).to(dev)
+    graph = model.prepare(ei, n)
+    x = torch.randn(n, c, device=dev)
+    plan = gwen_amd.StackForward(model.stack(), graph)
+    for _ in range(6):
+        plan.run(x)
+    for f, m in ((args.hbm_channels, args.hbm_members), (c, args.hbm_members_narrow)):
+        xs = torch.randn(m, n, f, device=dev)
+        for order in ("auto", "auto_x3", "auto_x6"):
+            layers = []
+            for _ in range(args.hbm_layers):
+                conv = gwen_amd.GCNConv(f, f).to(dev)
+                layers.append((conv.lin.weight.detach(), conv.bias.detach(), True, order))
+            st = gwen_amd.StackForward(layers, graph)
+            for _ in range(2):
+                st.run(xs)
+        del xs
+    if h in (32, 64, 128, 256):
+        for members in ((1, args.edge_mlp_members) if args.edge_mlp_members > 1 else (1,)):
+            g = interaction_graph(ei, n, n)
+            if members > 1:
+                g = g.batched(members)
+            net = InteractionNet(h).to(dev)
+            xe = torch.randn(g.num_dst, h, device=dev)
+            ef = torch.randn(g.num_edges, h, device=dev)
+            with torch.no_grad():
+                we, wa, wn, bn = net._weight_blocks()
+                p_ = ops.linear(xe, wn, bn, exact=False)
+                for _ in range(3):                                    # (collect_live_traffic: n1 = 3)
+                    mlp2(ef, we, net.edge_mlp[2].weight, net.edge_mlp[2].bias, g1=p_[:, :h], idx1=g.src,
+                         g2=p_[:, h:2 * h], idx2=g.dst, res=ef, graph=g)
+    torch.cuda.synchronize()
+
+
+def pmc_traffic(tag_prefixes):
+    """HBM-side bytes per launch of a kernel: from this run's own PMC passes (collect_live_traffic) when they
+    succeeded, else from the committed ones (profiles/traffic.json)."""
+    if LIVE_TRAFFIC is not None:
+        tf = LIVE_TRAFFIC["kernels"]
+    else:
+        try:
+            tf = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"]
+        except (OSError, KeyError, ValueError):
+            return None
     for k_, v in tf.items():
         for t in tag_prefixes:
             pre, suf = t if isinstance(t, tuple) else (t, "")
@@ -385,8 +522,7 @@ def hbm_leg(ga, mesh, graph, args, dev, f=None, m=None, what="c3 stack at c5's p
                      "compulsory_bytes_per_launch": comp, "avg_launch_us": round(avg * 1e6, 2),
                      "samples": cnt,
                      "traffic": (lambda v_: None if v_ is None else launches_per_layer * v_)(pmc_traffic(tags)),
-                     "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                       "of this command, gfx950 corrections applied)",
+                     "traffic_source": TRAFFIC_SOURCE,
                      "all_kernels_us": {f"{k[0]}[{k[1]}->{k[2]}]": round(v[1] / v[0] * 1e6, 2)
                                         for k, v in sorted(summ.items())}},
     }
@@ -636,8 +772,13 @@ def allgather_expectation(bytes_per_rank, world):
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     if "WORLD_SIZE" in os.environ or args.gpus == 1:
         library_info(args)                               # refuse a variant library before any work
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.workload == "c2" and not args.no_live_traffic \
+            and not (args.no_hbm_leg and args.no_edge_mlp) and "ROCPROF_OUTPUT_PATH" not in os.environ:
+        collect_live_traffic(args)                       # (not when this run is itself under rocprofv3)
     world, rank, dev = init_ranks(args)
     if args.workload == "c5":
         return run_c5(args, world, rank, dev)
@@ -766,7 +907,7 @@ def main():
         "bound": "l2", "kernel": f"{kind}_f32[{fin}->{fout}]", "achieved": round(achieved, 1),
         "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / L2_PEAK_GBS, 4),
         "traffic": pmc_traffic(tag) if default_c2 else None,
-        "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this command)",
+        "traffic_source": TRAFFIC_SOURCE,
         "l2_path_bytes_per_launch": b_l2, "frac_of_l2_gather_rate": round(achieved / L2_GATHER_GBS, 4),
         "compulsory_bytes_per_launch": b_comp,
         "frac_hbm_compulsory": round(b_comp / avg_s / 1e9 / HBM_PEAK_GBS, 4),

@@ -168,3 +168,33 @@ def test_two_ranks_self_launched_rehearsal(hip_lib, workload):
     assert ag["ranks_seen"] == 2 and ag["world_size"] == 2 and ag["backend"] == "gloo" and ag["bytes_per_rank"] > 0
     assert d["config"]["members"] == (2 if workload == "c2" else 4)
     assert d["value"] > 0 and "cpu_baseline" not in d and "hbm_leg" not in d
+
+
+@pytest.mark.gpu
+def test_default_line_carries_live_pmc_traffic_and_the_library_stamp():
+    """One short default-shaped run (N = 1): the contract keys, the library stamp, and `roofline.traffic` collected by
+    this very run (two rocprofv3 --pmc child passes) -- within 1.0 .. 1.25 x the compulsory bytes for the HBM-bound legs
+    (wasted re-reads would show here first); `ag["expected"]` on the N > 1 line is covered by the rehearsal test."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--hbm-steps", "3",
+           "--no-cpu-baseline", "--no-exact"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "library"):
+        assert key in d, key
+    assert d["steps"] == 20 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["library"]["variant"] is False and d["library"]["matches_sources"] is True
+    r = d["roofline"]
+    assert r["kernel_sum_us"] <= d["ms_per_step"] * 1e3 * 1.001 and 0 < r["bracket_scale"] <= 1.0
+    assert r["traffic_source"].startswith("LIVE"), r["traffic_source"]
+    leg = d["hbm_leg"]
+    assert leg["launches_per_layer"] == 1 and "f16x3" in leg["contraction"]
+    for lg in (leg, leg["tier_3xbf16"], d["hbm_leg_64ch"], d["hbm_leg_64ch"]["tier_3xbf16"]):
+        rr = lg["roofline"]
+        assert rr["traffic"] is not None and 1.0 <= rr["traffic"] / rr["compulsory_bytes_per_launch"] <= 1.25, rr
+    two = leg["precision_bf16x6_two_launches"]
+    assert two["launches_per_layer"] == 2 and two["roofline"]["traffic"] / two["roofline"]["compulsory_bytes_per_launch"] > 1.4
+    e8 = d["edge_mlp_block_8_members"]["roofline"]
+    assert e8["traffic"] is not None and 1.0 <= e8["traffic"] / e8["compulsory_bytes"] <= 1.25
