@@ -175,6 +175,10 @@ def test_wide_bipartite(ga):
         w, b = make_params(64, 128)
         got = ops.wide_layer(g, x, w.to(DEV), b.to(DEV), relu=True, contract="3xbf16")
         assert torch.equal(got, ops.layer_fused(g, x, w.to(DEV), b.to(DEV), relu=True))
+        # the default precision (f16x3 on K8) on a rectangular graph: fp32-class, i.e. within 2e-6 of K4's bf16x6
+        got16 = ops.wide_layer(g, x, w.to(DEV), b.to(DEV), relu=True)
+        assert rel_err(got16, ops.layer_fused(g, x, w.to(DEV), b.to(DEV), relu=True, contract="bf16x6")) <= 2e-6
+        assert torch.equal(got16, ops.wide_layer(g, x, w.to(DEV), b.to(DEV), relu=True, contract="f16x3"))
     assert tiled >= 1
 
 
