@@ -140,11 +140,12 @@ SIGNATURES = {
     "gwen_event_synchronize": (_int, [_vp]),
     "gwen_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "gwen_gcn_grad_workspace_floats": (_i64, [_i64, _i64, _i64]),
-    "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "gwen_gcn_grad_weight_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     "gwen_gcn_grad_bias_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "gwen_relu_backward_f32": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "gwen_gcn_grad_chunks": (_i64, [_i64]),
-    "gwen_gcn_grad_weight_partial_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "gwen_gcn_grad_weight_partial_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
+    "gwen_gcn_grad_weight_chunks": (_i64, [_i64, _i64, _i64, _int]),
     "gwen_gcn_grad_bias_partial_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "gwen_reduce_chunks_batched": (_int, [_vp, C.c_int32, _vp]),
     "gwen_transpose_batched": (_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),

@@ -137,8 +137,8 @@ extern "C" int gwen_gnn_backward_f32(const gwen_graph *graph_t, const gwen_layer
     }
     if (grad_W && grad_W[l]) {
       float *pw = scratch + P.part + P.pw_off[l];
-      GWEN_TRY(gwen_gcn_grad_weight_partial_f32(gh, xin, pw, rows, fi, fo, fo, fi, stream));
-      tasks[n_tasks++] = gwen_reduce_task{pw, grad_W[l], fi * fo, nc};
+      GWEN_TRY(gwen_gcn_grad_weight_partial_f32(gh, xin, pw, rows, fi, fo, fo, fi, cc, stream));
+      tasks[n_tasks++] = gwen_reduce_task{pw, grad_W[l], fi * fo, gwen_gcn_grad_weight_chunks(rows, fi, fo, cc)};
     }
     g = gx;
   }

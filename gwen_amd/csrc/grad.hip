@@ -5,11 +5,13 @@
 //   ReLU backward mask
 // (grad wrt the aggregated features is K2 on the transposed CSR; grad wrt x is K3 with W^T.)
 #include "common.h"
+#include "split.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kChunkRows = 256;    // rows reduced by one block before the cross-chunk stage
+constexpr int kWideChunkRows = 2048;   // ... by one block of the split kernel (k_grad_w_split)
 constexpr int kU = 8;              // independent loads in flight per thread in every reduction loop
 
 // One wave = one 32x32 tile of grad_W (rows = output channel, cols = input channel) over one chunk
@@ -55,6 +57,86 @@ __global__ __launch_bounds__(kThreads) void k_grad_w(const float *__restrict__ g
     const int o = o0 + (t & 3) + 8 * (t >> 2) + 4 * lh;
     if (o < Fout) d[(int64_t)o * Fin + i0 + li] = acc[t];
   }
+}
+
+// grad_W for WIDE layers on the split contractions (round 4).  At 256 channels the fp32-input MFMA above is the whole
+// cost of a training step's weight gradients (InteractionNet forecaster, 600 000 edge rows: 54 launches, 27 of the step's
+// 59 ms): 1/16 of the bf16 matrix rate, every operand value read by 8 waves.  Here one wave owns a 64 x 64 tile of
+// grad_W over a chunk of 2 048 rows: per 16 rows a lane reads its 8 rows of two 32-column pieces of g and of x (one
+// dword each, 128 contiguous bytes per half-wave: the same no-LDS access as above, four tiles' worth of products per
+// value instead of one), cuts them into NS bf16 images (split.h) and issues 4 x (3 | 6) v_mfma_f32_32x32x16_bf16.
+// NS = 2 (bf16x3) for layers on the "3xbf16" tier and the InteractionNet block, NS = 3 (bf16x6, operands kept to 2^-24)
+// for fp32-class layers; rows are summed in stored order by one wave, the chunks in a fixed order by k_reduce_*:
+// bitwise reproducible.  Widths: Fin, Fout multiples of 64 (no column guards); everything else stays on k_grad_w.
+template <int NS>
+__device__ inline f32x16 mma32_split(const gwen::bf16x8 (&a)[NS], const gwen::bf16x8 (&b)[NS], f32x16 d) {
+#pragma unroll
+  for (int t = NS - 1; t >= 0; --t)
+#pragma unroll
+    for (int i = 0; i <= t; ++i) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[t - i], d, 0, 0, 0);
+  return d;
+}
+
+template <int NS>
+__global__ __launch_bounds__(kThreads) void k_grad_w_split(const float *__restrict__ g, const float *__restrict__ x,
+                                                           float *__restrict__ dst, int64_t rows, int Fin, int Fout,
+                                                           int64_t ldg, int64_t ldx, int tiles_i, int ntiles) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.y * 4 + wave;
+  if (tile >= ntiles) return;
+  const int o0 = (tile / tiles_i) * 64, i0 = (tile % tiles_i) * 64;
+  const int64_t r0 = (int64_t)blockIdx.x * kWideChunkRows;
+  const int64_t r1 = (r0 + kWideChunkRows < rows) ? r0 + kWideChunkRows : rows;
+  const float *gp = g + o0 + li, *xp = x + i0 + li;
+  f32x16 acc[2][2] = {};
+  // this lane's 8 rows of a 16-row step: r + 8 lh .. + 7 (the k index of the MFMA's 8 values per lane), clamped to the
+  // chunk's last row and zeroed on the g side past it.  The next step's 32 values are requested before this step's
+  // products are issued.
+  float a[2][8], b[2][8];
+  auto load = [&](int64_t r) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t rr = r + 8 * lh + t, rc = rr < r1 ? rr : r1 - 1;
+      a[0][t] = gp[rc * ldg];
+      a[1][t] = gp[rc * ldg + 32];
+      b[0][t] = xp[rc * ldx];
+      b[1][t] = xp[rc * ldx + 32];
+    }
+  };
+  load(r0);
+  for (int64_t r = r0; r < r1; r += 16) {
+    gwen::bf16x8 ai[2][NS], bi[2][NS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float av[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) av[t] = r + 8 * lh + t < r1 ? a[s][t] : 0.0f;
+      gwen::split_images<8, NS>(av, ai[s]);
+      gwen::split_images<8, NS>(b[s], bi[s]);
+    }
+    if (r + 16 < r1) load(r + 16);
+#pragma unroll
+    for (int so = 0; so < 2; ++so)
+#pragma unroll
+      for (int si = 0; si < 2; ++si) acc[so][si] = mma32_split<NS>(ai[so], bi[si], acc[so][si]);
+  }
+  float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
+#pragma unroll
+  for (int so = 0; so < 2; ++so)
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int o = o0 + 32 * so + (t & 3) + 8 * (t >> 2) + 4 * lh;
+        d[(int64_t)o * Fin + i0 + 32 * si + li] = acc[so][si][t];
+      }
+}
+
+// the split kernel takes a weight gradient when its widths allow and the contraction is a bf16 split
+inline bool wide_grad(int64_t Fin, int64_t Fout, int contract) {
+  return (contract == GWEN_CONTRACT_BF16X3 || contract == GWEN_CONTRACT_BF16X6) && Fin % 64 == 0 && Fout % 64 == 0 &&
+         Fin * Fout >= 128 * 128;
 }
 
 // dst[j] = sum over chunks of partial[c][j], in a fixed order: 16 phases (phase p adds chunks p, p+16,
@@ -123,6 +205,35 @@ __global__ void k_relu_bwd(const float *__restrict__ y, const float *__restrict_
 }
 
 inline int64_t nchunks_for(int64_t rows) { return rows > 0 ? (rows + kChunkRows - 1) / kChunkRows : 1; }
+inline int64_t nchunks_w(int64_t rows, int64_t Fin, int64_t Fout, int contract) {     // partial slots of a weight gradient
+  if (!wide_grad(Fin, Fout, contract)) return nchunks_for(rows);
+  return rows > 0 ? (rows + kWideChunkRows - 1) / kWideChunkRows : 1;
+}
+
+// stage 1 of grad_W into `dst` ([slots, Fout * Fin]; slots = nchunks_w)
+int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int64_t Fin, int64_t Fout, int64_t ldg,
+                  int64_t ldx, int contract, hipStream_t st) {
+  if (wide_grad(Fin, Fout, contract)) {
+    const int64_t nc = nchunks_w(rows, Fin, Fout, contract);
+    const int tiles_i = (int)(Fin / 64), ntiles = (int)(Fin / 64 * (Fout / 64));
+    if (nc > 0x7fffffffLL || (ntiles + 3) / 4 > 65535) return GWEN_ERANGE;
+    dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
+    if (contract == GWEN_CONTRACT_BF16X6)
+      k_grad_w_split<3><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+    else
+      k_grad_w_split<2><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+    GWEN_LAUNCH_CHECK();
+    return GWEN_OK;
+  }
+  const int64_t nc = nchunks_for(rows);
+  const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
+  const int64_t ntiles = (int64_t)tiles_i * tiles_o;
+  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL) return GWEN_ERANGE;
+  dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
+  k_grad_w<<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, (int)ntiles);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
 
 // k_reduce_chunks for up to GWEN_MAX_REDUCE_TASKS (partial, dst, count, nchunks) tasks in ONE launch: the
 // finish stages of every grad_W / grad_b of a backward pass (blockIdx.y = task).
@@ -176,23 +287,20 @@ extern "C" int64_t gwen_gcn_grad_workspace_floats(int64_t rows, int64_t Fin, int
 
 extern "C" int gwen_gcn_grad_weight_f32(const float *g, const float *x, float *grad_W,
                                         int64_t rows, int64_t Fin, int64_t Fout, int64_t ldg,
-                                        int64_t ldx, float *partial, gwen_stream_t stream_) {
-  if (rows < 0 || Fin < 0 || Fout < 0 || ldg < Fout || ldx < Fin) return GWEN_EINVAL;
+                                        int64_t ldx, float *partial, int contract, gwen_stream_t stream_) {
+  if (rows < 0 || Fin < 0 || Fout < 0 || ldg < Fout || ldx < Fin || contract < 0 || contract > GWEN_CONTRACT_F16X3)
+    return GWEN_EINVAL;
   if (Fin == 0 || Fout == 0) return GWEN_OK;
   if (!grad_W || (rows > 0 && (!g || !x))) return GWEN_EINVAL;
-  if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
+  if (Fin >= (1 << 30) || Fout >= (1 << 30) || (Fin * Fout + 15) / 16 > 0x7fffffffLL) return GWEN_ERANGE;
   hipStream_t st = gwen_stream(stream_);
-  const int64_t nc = nchunks_for(rows);
-  const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
-  const int64_t ntiles = (int64_t)tiles_i * tiles_o;
-  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL || (Fin * Fout + 15) / 16 > 0x7fffffffLL)
-    return GWEN_ERANGE;
+  contract = gwen_dense_contract(contract);
+  if (rows == 0) return (int)hipMemsetAsync(grad_W, 0, sizeof(float) * Fin * Fout, st);
+  const int64_t nc = nchunks_w(rows, Fin, Fout, contract);
   if (nc > 1 && !partial) return GWEN_EINVAL;
   float *dst = nc > 1 ? partial : grad_W;
-  dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
-  k_grad_w<<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i,
-                                      (int)ntiles);
-  GWEN_LAUNCH_CHECK();
+  const int rc = launch_grad_w(g, x, dst, rows, Fin, Fout, ldg, ldx, contract, st);
+  if (rc != GWEN_OK) return rc;
   if (nc > 1) {
     const int64_t count = Fin * Fout;
     k_reduce_chunks<<<(unsigned)((count + 15) / 16), kThreads, 0, st>>>(partial, grad_W, count, (int)nc);
@@ -237,21 +345,18 @@ extern "C" int gwen_relu_backward_f32(const float *y, const float *g, float *gin
 // Stage 1 only: per-chunk partial sums [nchunks, Fout * Fin] / [nchunks, F] (nchunks = gwen_gcn_grad_chunks(rows));
 // the fixed-order finish of MANY such reductions is one gwen_reduce_chunks_batched launch.
 extern "C" int64_t gwen_gcn_grad_chunks(int64_t rows) { return nchunks_for(rows); }
+extern "C" int64_t gwen_gcn_grad_weight_chunks(int64_t rows, int64_t Fin, int64_t Fout, int contract) {
+  return nchunks_w(rows, Fin, Fout, gwen_dense_contract(contract));
+}
 
 extern "C" int gwen_gcn_grad_weight_partial_f32(const float *g, const float *x, float *partial, int64_t rows,
-                                                int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx,
+                                                int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx, int contract,
                                                 gwen_stream_t stream_) {
-  if (rows <= 0 || Fin <= 0 || Fout <= 0 || ldg < Fout || ldx < Fin || !g || !x || !partial) return GWEN_EINVAL;
+  if (rows <= 0 || Fin <= 0 || Fout <= 0 || ldg < Fout || ldx < Fin || !g || !x || !partial || contract < 0 ||
+      contract > GWEN_CONTRACT_F16X3)
+    return GWEN_EINVAL;
   if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
-  const int64_t nc = nchunks_for(rows);
-  const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
-  const int64_t ntiles = (int64_t)tiles_i * tiles_o;
-  if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL) return GWEN_ERANGE;
-  dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
-  k_grad_w<<<grid, kThreads, 0, gwen_stream(stream_)>>>(g, x, partial, rows, (int)Fin, (int)Fout, ldg, ldx,
-                                                        tiles_i, (int)ntiles);
-  GWEN_LAUNCH_CHECK();
-  return GWEN_OK;
+  return launch_grad_w(g, x, partial, rows, Fin, Fout, ldg, ldx, gwen_dense_contract(contract), gwen_stream(stream_));
 }
 
 extern "C" int gwen_gcn_grad_bias_partial_f32(const float *g, float *partial, int64_t rows, int64_t F,

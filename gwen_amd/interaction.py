@@ -327,7 +327,8 @@ class _InteractionNetFunction(torch.autograd.Function):
         edge MLP:  g_pre1 = (g_m W2) * act'(pre1);  g_e = ge + g_pre1 We
         nodes:     G_d = sum of g_pre1 over a target's edges, G_s over a source's   (K2 over ``EdgeGraph.segments``:
                    stored order, no atomics);  g_x_dst += G_d Wd,  g_x_src = G_s Ws
-        weights:   every grad_W = (gradient rows)^T (input rows), grad_b = column sums   (fixed-order reductions)
+        weights:   every grad_W = (gradient rows)^T (input rows), grad_b = column sums   (fixed-order reductions; the
+                   wide ones -- multiples of 64 from 128 x 128 -- on the block's own bf16x3 split: csrc/grad.hip)
     Every launch is atomic-free with a fixed summation order: two backward runs are bitwise equal.  BUILD-DEFINED
     like the block (the reference has no edge MLP); gradients are tested against fp64 autograd of the oracle."""
 
@@ -367,24 +368,24 @@ class _InteractionNetFunction(torch.autograd.Function):
             del m
             h3, d3 = _act_pair(lin(agg, wa), act, lin(x_dst, wx_, b3))
             # ---- node MLP -----------------------------------------------------------------------------------------
-            g_b4, g_w4 = ops.grad_bias(gx), ops.grad_weight(gx, h3)
+            g_b4, g_w4 = ops.grad_bias(gx), ops.grad_weight(gx, h3, _BWD_CONTRACT)
             g_pre3 = _ew(_lib.EW_MUL, lin(gx, tr(w4)), d3)
             del h3, d3
             g_b3 = ops.grad_bias(g_pre3)
-            g_w3 = torch.cat([ops.grad_weight(g_pre3, x_dst), ops.grad_weight(g_pre3, agg)], dim=1)
+            g_w3 = torch.cat([ops.grad_weight(g_pre3, x_dst, _BWD_CONTRACT), ops.grad_weight(g_pre3, agg, _BWD_CONTRACT)], dim=1)
             g_agg = lin(g_pre3, tr(wa))
             g_xd = _ew(_lib.EW_ADD, lin(g_pre3, tr(wx_)), gx)
             del g_pre3, agg
             # ---- messages and edge MLP ----------------------------------------------------------------------------
             g_m = _gather_add(ge, g_agg, g.dst, g.inv_degree() if mean else None)
-            g_b2, g_w2 = ops.grad_bias(g_m), ops.grad_weight(g_m, h1)
+            g_b2, g_w2 = ops.grad_bias(g_m), ops.grad_weight(g_m, h1, _BWD_CONTRACT)
             g_pre1 = _ew(_lib.EW_MUL, lin(g_m, tr(w2)), d1)
             del g_m, h1, d1, g_agg
             g_b1 = ops.grad_bias(g_pre1)
             big_d = _segsum(g.segments("dst"), g_pre1, n_dst)          # per target: sum over its in-edges
             big_s = _segsum(g.segments("src"), g_pre1, n_src)          # per source: sum over its out-edges
-            g_w1 = torch.cat([ops.grad_weight(g_pre1, e), ops.grad_weight(big_s, x_src),
-                              ops.grad_weight(big_d, x_dst)], dim=1)
+            g_w1 = torch.cat([ops.grad_weight(g_pre1, e, _BWD_CONTRACT), ops.grad_weight(big_s, x_src, _BWD_CONTRACT),
+                              ops.grad_weight(big_d, x_dst, _BWD_CONTRACT)], dim=1)
             g_e = lin(g_pre1, tr(we))
             if has_ge:
                 g_e = _ew(_lib.EW_ADD, g_e, ge)

@@ -144,7 +144,7 @@ class LinearFunction(torch.autograd.Function):
         if ctx.relu:
             g = relu_backward(y, g)
         gx = linear(g, weight.t().contiguous(), contract=ctx.contract) if ctx.needs_input_grad[0] else None
-        gw = grad_weight(g, x) if ctx.needs_input_grad[1] else None
+        gw = grad_weight(g, x, ctx.contract) if ctx.needs_input_grad[1] else None
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None
 
@@ -298,8 +298,10 @@ def _grad_workspace(rows: int, fin: int, fout: int, dev) -> Tensor:
     return torch.empty(n, dtype=torch.float32, device=dev)
 
 
-def grad_weight(g: Tensor, x: Tensor) -> Tensor:
-    """grad_W [Fout, Fin] = g^T @ x over all leading rows."""
+def grad_weight(g: Tensor, x: Tensor, contract: Optional[str] = None) -> Tensor:
+    """grad_W [Fout, Fin] = g^T @ x over all leading rows.  ``contract``: the contraction of the layer the gradient
+    belongs to -- None / "fp32": exact fp32 products; "bf16x6" / "f16x3" / "3xbf16": the split contractions where the
+    widths allow (multiples of 64 from 128 x 128 up: 3 - 6 x faster at 256 channels), the fp32 MFMA elsewhere."""
     g = g.contiguous(); x = x.contiguous()
     fout, fin = g.size(-1), x.size(-1)
     rows = math.prod(g.shape[:-1])
@@ -307,7 +309,7 @@ def grad_weight(g: Tensor, x: Tensor) -> Tensor:
     ws = _grad_workspace(rows, fin, fout, g.device)
     with torch.cuda.device(g.device):
         rc = _lib.lib().gwen_gcn_grad_weight_f32(_ptr(g), _ptr(x), _ptr(out), rows, fin, fout, fout,
-                                                 fin, _ptr(ws), _stream(g.device))
+                                                 fin, _ptr(ws), _contract_code(contract), _stream(g.device))
     _lib.check(rc, "gwen_gcn_grad_weight_f32")
     return out
 
@@ -404,12 +406,12 @@ class GCNLayerFunction(torch.autograd.Function):
         if ctx.order in ("transform_first", "fused", "fused_x3", "fused_exact", "small", "wide"):   # out = act(A~ x W^T + b) either way
             gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
             if ctx.needs_input_grad[1]:
-                gw = grad_weight(gh, saved_in)                     # gh^T x
+                gw = grad_weight(gh, saved_in, ctx.contract)       # gh^T x
             if ctx.needs_input_grad[0]:
                 gx = linear(gh, weight.t().contiguous(), contract=ctx.contract)        # gh W (split-K)
         else:
             if ctx.needs_input_grad[1]:
-                gw = grad_weight(g, saved_in)                      # g^T (A~ x)
+                gw = grad_weight(g, saved_in, ctx.contract)        # g^T (A~ x)
             if ctx.needs_input_grad[0]:
                 gagg = linear(g, weight.t().contiguous(), contract=ctx.contract)       # g W
                 gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)

@@ -374,7 +374,11 @@ int gwen_event_elapsed_ms(void *start, void *stop, float *ms /* host out */);
 /* ---------------------------------------------------------------------------------------------
  * Backward pieces (autograd of the layer; the reference trains through it:
  * /root/reference/src/gwen/models_gnn.py:372 loss.backward()).
- *   grad_W[Fout,Fin] = g^T @ x   (g [rows,Fout], x [rows,Fin]); deterministic two-stage reduce.
+ *   grad_W[Fout,Fin] = g^T @ x   (g [rows,Fout], x [rows,Fin]); deterministic two-stage reduce.  contract: the
+ *                      contraction of the layer the gradient belongs to -- GWEN_CONTRACT_F32: fp32-input MFMA (exact
+ *                      fp32 products); _BF16X3 / _BF16X6 (_F16X3 = _BF16X6 here): the split contractions on 64 x 64
+ *                      tiles of grad_W where Fin, Fout are multiples of 64 and Fin * Fout >= 128^2 (at 256 channels
+ *                      3 - 6 x the fp32 MFMA's rate), the fp32 MFMA elsewhere.
  *   grad_b[F]        = column sums of g.
  *   relu mask        : g *= (y > 0).
  * partial: fp32 workspace of gwen_gcn_grad_workspace_floats(rows, Fin, Fout) elements.
@@ -382,13 +386,14 @@ int gwen_event_elapsed_ms(void *start, void *stop, float *ms /* host out */);
 int64_t gwen_gcn_grad_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout);
 int gwen_gcn_grad_weight_f32(const float *g, const float *x, float *grad_W, int64_t rows,
                              int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx, float *partial,
-                             gwen_stream_t stream);
+                             int contract, gwen_stream_t stream);
 int gwen_gcn_grad_bias_f32(const float *g, float *grad_b, int64_t rows, int64_t F, int64_t ldg,
                            float *partial, gwen_stream_t stream);
 int gwen_relu_backward_f32(const float *y, const float *g, float *gin, int64_t count,
                            gwen_stream_t stream);
 /* Building blocks of gwen_gnn_backward_f32: stage 1 of the two reductions alone (per-chunk partial sums,
- * [gwen_gcn_grad_chunks(rows), Fout * Fin] and [.., F]), the fixed-order finish of up to
+ * [gwen_gcn_grad_weight_chunks(rows, Fin, Fout, contract) <= gwen_gcn_grad_chunks(rows), Fout * Fin] and
+ * [gwen_gcn_grad_chunks(rows), F]), the fixed-order finish of up to
  * GWEN_MAX_REDUCE_TASKS such reductions in ONE launch (dst[j] = sum over chunks of partial[c * count + j]),
  * and up to GWEN_MAX_REDUCE_TASKS small transposes (wt [cols, rows] = w [rows, cols]^T) in one launch.
  * tasks / w / wt / rows / cols are HOST arrays (they travel as kernel arguments). */
@@ -399,8 +404,9 @@ typedef struct gwen_reduce_task {
   int64_t count, nchunks;
 } gwen_reduce_task;
 int64_t gwen_gcn_grad_chunks(int64_t rows);
+int64_t gwen_gcn_grad_weight_chunks(int64_t rows, int64_t Fin, int64_t Fout, int contract);
 int gwen_gcn_grad_weight_partial_f32(const float *g, const float *x, float *partial, int64_t rows,
-                                     int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx,
+                                     int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx, int contract,
                                      gwen_stream_t stream);
 int gwen_gcn_grad_bias_partial_f32(const float *g, float *partial, int64_t rows, int64_t F, int64_t ldg,
                                    gwen_stream_t stream);
