@@ -6,6 +6,7 @@
 // (grad wrt the aggregated features is K2 on the transposed CSR; grad wrt x is K3 with W^T.)
 #include "common.h"
 #include "split.h"
+#include "rows_common.h"
 
 namespace {
 
@@ -133,6 +134,83 @@ __global__ __launch_bounds__(kThreads) void k_grad_w_split(const float *__restri
       }
 }
 
+// The same tiles with the operands STAGED THROUGH LDS: k_grad_w_split reads every value with its own dword load -- 32
+// vector-memory instructions per wave and 16-row step, which is what bounds it (627 us for 600 000 x 256 x 256 on bf16x3
+// where the matrix pipe needs ~160).  Here a block owns BO x BI outputs (one wave per 64 x 64 piece); per 16-row step the
+// 16 x (BO + BI) fp32 values arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, (BO + BI) / 16 of
+// them per BLOCK) into one of two buffers while the step before is being contracted, and a lane reads its 8 rows of a
+// column from the row-major tile (consecutive lanes = consecutive dwords: conflict-free).  One barrier per step; the
+// DMAs are inline asm (hipcc neither counts nor drains them) and the only visible vector-memory instructions are the
+// tile's stores after the loop.
+template <int NS, int BO, int BI>
+__global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
+    const float *__restrict__ g, const float *__restrict__ x, float *__restrict__ dst, int64_t rows, int Fin, int Fout,
+    int64_t ldg, int64_t ldx, int tiles_i) {
+  constexpr int NWB = (BO / 64) * (BI / 64);                 // waves per block
+  constexpr int kStepBytes = 16 * (BO + BI) * 4;             // one step's tiles: g [16][BO] | x [16][BI]
+  constexpr int PG = BO / 16, NPC = (BO + BI) / 16, PPW = NPC / NWB;     // 1-KiB pieces: of g, in all, per wave
+  static_assert(NPC % NWB == 0, "the pieces must deal out over the waves");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * kStepBytes];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wo = wave / (BI / 64), wi = wave % (BI / 64);
+  const int o0 = ((int)blockIdx.y / tiles_i) * BO, i0 = ((int)blockIdx.y % tiles_i) * BI;
+  const int64_t r0 = (int64_t)blockIdx.x * kWideChunkRows;
+  const int64_t r1 = (r0 + kWideChunkRows < rows) ? r0 + kWideChunkRows : rows;
+  const char *gb = uniform_ptr(g + r0 * ldg + o0), *xb = uniform_ptr(x + r0 * ldx + i0);
+  const int nsteps = (int)((r1 - r0 + 15) / 16), nrows = (int)(r1 - r0);
+  // step st's tiles -> buffer buf: piece p of g holds 1024 / (4 BO) rows of BO floats (lane l: 16 B at column 4 (l % (BO / 4))
+  // of row l / (BO / 4)); rows past the chunk are clamped to its last row (and zeroed when they are read)
+  auto issue = [&](int st, int buf) {
+    static_for<PPW>([&](auto qq) {
+      const int piece = wave * PPW + decltype(qq)::value;              // wave-uniform
+      const bool is_g = piece < PG;
+      const int pp = is_g ? piece : piece - PG;
+      const int lpr = (is_g ? BO : BI) / 4;                          // lanes per row
+      int row = st * 16 + pp * (64 / lpr) + lane / lpr;
+      row = row < nrows ? row : nrows - 1;
+      const uint32_t voff = (uint32_t)(((int64_t)row * (is_g ? ldg : ldx) + 4 * (lane % lpr)) * 4);
+      glds16<0>(is_g ? gb : xb, voff, lds0 + buf * kStepBytes + (is_g ? 0 : 16 * BO * 4) + pp * 1024);
+    });
+  };
+  f32x16 acc[2][2] = {};
+  issue(0, 0);
+  for (int st = 0; st < nsteps; ++st) {
+    wait_vm<0>();                                   // this wave's pieces of step st (issued a step ago) have landed
+    __syncthreads();                                // ... everyone's; and everyone is done reading the other buffer
+    if (st + 1 < nsteps) issue(st + 1, (st + 1) & 1);
+    const float *lg = reinterpret_cast<const float *>(lds + (st & 1) * kStepBytes), *lx = lg + 16 * BO;
+    gwen::bf16x8 ai[2][NS], bi[2][NS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float a = lg[(8 * lh + t) * BO + 64 * wo + 32 * s + li];
+        av[t] = st * 16 + 8 * lh + t < nrows ? a : 0.0f;
+        bv[t] = lx[(8 * lh + t) * BI + 64 * wi + 32 * s + li];
+      }
+      gwen::split_images<8, NS>(av, ai[s]);
+      gwen::split_images<8, NS>(bv, bi[s]);
+    }
+#pragma unroll
+    for (int so = 0; so < 2; ++so)
+#pragma unroll
+      for (int si = 0; si < 2; ++si) acc[so][si] = mma32_split<NS>(ai[so], bi[si], acc[so][si]);
+  }
+  float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
+#pragma unroll
+  for (int so = 0; so < 2; ++so)
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int o = o0 + 64 * wo + 32 * so + (t & 3) + 8 * (t >> 2) + 4 * lh;
+        d[(int64_t)o * Fin + i0 + 64 * wi + 32 * si + li] = acc[so][si][t];
+      }
+}
+
 // the split kernel takes a weight gradient when its widths allow and the contraction is a bf16 split
 inline bool wide_grad(int64_t Fin, int64_t Fout, int contract) {
   return (contract == GWEN_CONTRACT_BF16X3 || contract == GWEN_CONTRACT_BF16X6) && Fin % 64 == 0 && Fout % 64 == 0 &&
@@ -215,13 +293,33 @@ int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int6
                   int64_t ldx, int contract, hipStream_t st) {
   if (wide_grad(Fin, Fout, contract)) {
     const int64_t nc = nchunks_w(rows, Fin, Fout, contract);
-    const int tiles_i = (int)(Fin / 64), ntiles = (int)(Fin / 64 * (Fout / 64));
-    if (nc > 0x7fffffffLL || (ntiles + 3) / 4 > 65535) return GWEN_ERANGE;
-    dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
-    if (contract == GWEN_CONTRACT_BF16X6)
-      k_grad_w_split<3><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
-    else
-      k_grad_w_split<2><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+    if (nc > 0x7fffffffLL || ldg * 4 * kWideChunkRows >= (int64_t(1) << 31) || ldx * 4 * kWideChunkRows >= (int64_t(1) << 31))
+      return GWEN_ERANGE;
+    if (!gwen_aligned(g, 16) || !gwen_aligned(x, 16) || ldg % 4 || ldx % 4) {     // (the DMA moves 16-byte pieces)
+      const int tiles_i = (int)(Fin / 64), ntiles = (int)(Fin / 64 * (Fout / 64));
+      if ((ntiles + 3) / 4 > 65535) return GWEN_ERANGE;
+      dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
+      if (contract == GWEN_CONTRACT_BF16X6)
+        k_grad_w_split<3><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+      else
+        k_grad_w_split<2><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+      GWEN_LAUNCH_CHECK();
+      return GWEN_OK;
+    }
+#define GWEN_GW(NS_, BO_, BI_)                                                                                     \
+  do {                                                                                                             \
+    const int ti = (int)(Fin / BI_);                                                                               \
+    const int64_t nt = (int64_t)ti * (Fout / BO_);                                                                 \
+    if (nt > 65535) return GWEN_ERANGE;                                                                            \
+    k_grad_w_lds<NS_, BO_, BI_><<<dim3((unsigned)nc, (unsigned)nt), (BO_ / 64) * (BI_ / 64) * 64, 0, st>>>(        \
+        g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, ti);                                                       \
+  } while (0)
+    const bool o128 = Fout % 128 == 0, i128 = Fin % 128 == 0, x6 = contract == GWEN_CONTRACT_BF16X6;
+    if (o128 && i128) { if (x6) GWEN_GW(3, 128, 128); else GWEN_GW(2, 128, 128); }
+    else if (o128) { if (x6) GWEN_GW(3, 128, 64); else GWEN_GW(2, 128, 64); }
+    else if (i128) { if (x6) GWEN_GW(3, 64, 128); else GWEN_GW(2, 64, 128); }
+    else { if (x6) GWEN_GW(3, 64, 64); else GWEN_GW(2, 64, 64); }
+#undef GWEN_GW
     GWEN_LAUNCH_CHECK();
     return GWEN_OK;
   }
