@@ -252,7 +252,7 @@ class InteractionNet(nn.Module):
         return self._forward_k6(x_src, x_dst, e, graph, update_edges)
 
     def _forward_k6(self, x_src: Tensor, x_dst: Tensor, e: Tensor, graph: EdgeGraph,
-                    update_edges: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+                    update_edges: bool = True, return_agg: bool = False):
         f = self.channels
         we, wa, wn, bn = self._weight_blocks()
         if x_src is x_dst:                                   # mesh -> mesh: one launch, [N, 3F]
@@ -267,7 +267,7 @@ class InteractionNet(nn.Module):
                           graph=graph, mean=self.aggr == "mean", want_out=update_edges)
         x_new, _ = mlp2(agg, wa, self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
                         res=x_dst, act=self.activation)
-        return x_new, e_new
+        return (x_new, e_new, agg) if return_agg else (x_new, e_new)
 
 
 # ---- pieces of the backward (csrc/interact_bwd.hip + K2 / K3 / the gradient reductions) -------------------------
@@ -320,8 +320,9 @@ def _segsum(seg: Tuple[Tensor, Tensor, Tensor], h: Tensor, rows: int) -> Tensor:
 
 class _InteractionNetFunction(torch.autograd.Function):
     """Training through an InteractionNet block, forward AND backward on libgwen_hip.so.  The forward runs on K6 and
-    keeps no intermediate; the backward recomputes the two hidden layers (K3 + ``gwen_act_pair_f32``, which also
-    yields the activation's derivative) and then walks the block in reverse:
+    keeps ONE intermediate, the aggregated messages (a node-sized array the edge kernel produces anyway: keeping it
+    saves the backward an edge-sized projection and a segmented sum); the backward recomputes the two hidden layers
+    (K3 + ``gwen_act_pair_f32``, which also yields the activation's derivative) and then walks the block in reverse:
         node MLP:  g_pre3 = (gx W4) * act'(pre3);   g_agg = g_pre3 Wa;   g_x += gx + g_pre3 Wx
         messages:  g_m[e] = ge[e] + g_agg[dst(e)] (/ degree for the mean)          (``gwen_gather_add_f32``)
         edge MLP:  g_pre1 = (g_m W2) * act'(pre1);  g_e = ge + g_pre1 We
@@ -335,9 +336,9 @@ class _InteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, graph, update_edges, same, x_src, x_dst, e, *params):
         with torch.no_grad():
-            x_new, e_new = net._forward_k6(x_dst if same else x_src, x_dst, e, graph, update_edges)
+            x_new, e_new, agg = net._forward_k6(x_dst if same else x_src, x_dst, e, graph, update_edges, return_agg=True)
         ctx.net, ctx.graph, ctx.update_edges, ctx.same = net, graph, update_edges, same
-        ctx.save_for_backward(x_src, x_dst, e, *params)
+        ctx.save_for_backward(x_src, x_dst, e, agg, *params)
         if e_new is None:
             e_new = e.new_empty(0)
             ctx.mark_non_differentiable(e_new)
@@ -345,7 +346,7 @@ class _InteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gx, ge):
-        x_src, x_dst, e, w1, b1, w2, b2, w3, b3, w4, b4 = ctx.saved_tensors
+        x_src, x_dst, e, agg, w1, b1, w2, b2, w3, b3, w4, b4 = ctx.saved_tensors
         net, g, same = ctx.net, ctx.graph, ctx.same
         f, act, mean = net.channels, net.activation, net.aggr == "mean"
         n_src, n_dst = g.num_src, g.num_dst
@@ -362,10 +363,7 @@ class _InteractionNetFunction(torch.autograd.Function):
             ps = lin(x_src, ws_)
             pd = lin(x_dst, wd_, b1)
             h1, d1 = _act_pair(lin(e, we), act, ps, g.src, pd, g.dst)
-            del ps, pd
-            m = lin(h1, w2, b2)
-            agg = _segsum(g.segments("dst", mean), m, n_dst)
-            del m
+            del ps, pd                                   # (agg = sum / mean of the messages: kept by the forward)
             h3, d3 = _act_pair(lin(agg, wa), act, lin(x_dst, wx_, b3))
             # ---- node MLP -----------------------------------------------------------------------------------------
             g_b4, g_w4 = ops.grad_bias(gx), ops.grad_weight(gx, h3, _BWD_CONTRACT)
@@ -381,8 +379,8 @@ class _InteractionNetFunction(torch.autograd.Function):
             g_b2, g_w2 = ops.grad_bias(g_m), ops.grad_weight(g_m, h1, _BWD_CONTRACT)
             g_pre1 = _ew(_lib.EW_MUL, lin(g_m, tr(w2)), d1)
             del g_m, h1, d1, g_agg
-            g_b1 = ops.grad_bias(g_pre1)
             big_d = _segsum(g.segments("dst"), g_pre1, n_dst)          # per target: sum over its in-edges
+            g_b1 = ops.grad_bias(big_d)                                # = column sums of g_pre1, over N_dst rows instead of E
             big_s = _segsum(g.segments("src"), g_pre1, n_src)          # per source: sum over its out-edges
             g_w1 = torch.cat([ops.grad_weight(g_pre1, e, _BWD_CONTRACT), ops.grad_weight(big_s, x_src, _BWD_CONTRACT),
                               ops.grad_weight(big_d, x_dst, _BWD_CONTRACT)], dim=1)
