@@ -360,11 +360,20 @@ class _InteractionNetFunction(torch.autograd.Function):
             we, wa = w1[:, :f].contiguous(), w3[:, f:].contiguous()
             ws_, wd_, wx_ = w1[:, f:2 * f].contiguous(), w1[:, 2 * f:].contiguous(), w3[:, :f].contiguous()
             # ---- the two hidden layers again (the forward kept nothing) -----------------------------------------
-            ps = lin(x_src, ws_)
-            pd = lin(x_dst, wd_, b1)
+            # the node-side projections as the forward makes them: ONE stacked launch [Ps | Pd | Q] when x_src is x_dst
+            # (two when not); the kernels below read the column blocks through a row stride
+            _, _, wn, bn = net._weight_blocks()
+            if same:
+                pall = lin(x_dst, wn, bn)
+                ps, pd, q = pall[:, :f], pall[:, f:2 * f], pall[:, 2 * f:]
+            else:
+                ps = lin(x_src, wn[:f])
+                pall = lin(x_dst, wn[f:], bn[f:])
+                pd, q = pall[:, :f], pall[:, f:]
             h1, d1 = _act_pair(lin(e, we), act, ps, g.src, pd, g.dst)
             del ps, pd                                   # (agg = sum / mean of the messages: kept by the forward)
-            h3, d3 = _act_pair(lin(agg, wa), act, lin(x_dst, wx_, b3))
+            h3, d3 = _act_pair(lin(agg, wa), act, q)
+            del pall, q
             # ---- node MLP -----------------------------------------------------------------------------------------
             g_b4, g_w4 = ops.grad_bias(gx), ops.grad_weight(gx, h3, _BWD_CONTRACT)
             g_pre3 = _ew(_lib.EW_MUL, lin(gx, tr(w4)), d3)
