@@ -166,6 +166,9 @@ SIGNATURES = {
     "gwen_act_pair_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _vp]),
     "gwen_gather_add_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "gwen_ew_f32": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
+    "gwen_mlp2_bwd_supported": (_int, [_i64]),
+    "gwen_mlp2_bwd_rows": (_i64, [_i64]),
+    "gwen_mlp2_bwd_f32": (_int, [_vp] * 5 + [_i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, C.c_size_t, _vp]),
     "gwen_masked_l1_workspace_floats": (_i64, []),
     "gwen_masked_l1_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
 }

@@ -528,6 +528,37 @@ extern "C" int gwen_edge_tiles(const int32_t *rowptr, int64_t N, int64_t E, int6
   return GWEN_OK;
 }
 
+// The edge-level half of the block's backward as ONE launch of the row-stationary kernel (interact_rows.hip, HID):
+//     g_pre1 = (ge W2 + T[dst]) * d1        T = (g_agg, scaled for the mean) W2 per NODE: ge + g_agg[dst] never exists
+//     g_e    = ge + g_pre1 We
+// W2t = W2^T and Wet = We^T, [F, F] row-major (row = output column of the contraction); d1 = act'(pre1) [R, F];
+// g_pre1 has gwen_mlp2_bwd_rows(R) rows (whole passes: the kernel stores every lane), g_e has R.  F in {64, 256}.
+int gwen_mlp2_rows_bwd_launch(int F, const float *ge, const float *W2t, const float *d1, const float *T,
+                              const int32_t *dst, const float *Wet, float *hid, float *out, int64_t R, void *workspace,
+                              uint32_t ldbT, hipStream_t st);
+extern "C" int64_t gwen_mlp2_bwd_rows(int64_t R) {
+  const int64_t rows = gwen_mlp2_rows_f();
+  return R <= 0 ? 0 : (R + rows - 1) / rows * rows;
+}
+extern "C" int gwen_mlp2_bwd_supported(int64_t F) { return F == 64 || F == 256 ? 1 : 0; }
+extern "C" int gwen_mlp2_bwd_f32(const float *ge, const float *W2t, const float *d1, const float *T, const int32_t *dst,
+                                 int64_t T_rows, int64_t ldT, const float *Wet, float *g_pre1, float *g_e, int64_t R,
+                                 int64_t F, void *workspace, size_t workspace_bytes, gwen_stream_t stream_) {
+  if (R < 0 || T_rows < 0 || !gwen_mlp2_bwd_supported(F)) return GWEN_EINVAL;
+  if (R == 0) return GWEN_OK;
+  if (!ge || !W2t || !d1 || !T || !dst || !Wet || !g_pre1 || !g_e || ldT < F || ldT % 4) return GWEN_EINVAL;
+  if (g_pre1 == ge || g_pre1 == d1 || g_pre1 == g_e || g_e == d1) return GWEN_EINVAL;      // g_e may alias ge row for row
+  if (R >= (int64_t(1) << 31) - kMaxRows || T_rows * ldT * 4 >= (int64_t(1) << 32) || R * F * 4 >= (int64_t(1) << 32))
+    return GWEN_ERANGE;              // 32-bit byte offsets into the tables (d1 is read as a table, row for row)
+  const int64_t need = gwen_mlp2_workspace_bytes(F);
+  if (need > 0 && (!workspace || (int64_t)workspace_bytes < need)) return GWEN_ENOSPACE;
+  const void *al[] = {ge, W2t, d1, T, Wet, g_pre1, g_e, need > 0 ? workspace : nullptr};
+  for (const void *p : al)
+    if (p && !gwen_aligned(p, 16)) return GWEN_EINVAL;
+  return gwen_mlp2_rows_bwd_launch((int)F, ge, W2t, d1, T, dst, Wet, g_pre1, g_e, R, workspace, (uint32_t)(ldT * 4),
+                                   gwen_stream(stream_));
+}
+
 extern "C" int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_t *idx1,
                              int64_t G1_rows, int64_t ldg1, const float *G2, const int32_t *idx2,
                              int64_t G2_rows, int64_t ldg2,

@@ -116,16 +116,22 @@ struct Pass {
 // visible (hipcc-counted) vector-memory instructions step si of a pass issues after its DMAs: the first
 // contraction's steps load the G1 rows (4 tiles a step, steps 0-3) and, with a residual other than A, its rows;
 // the second one's load the next pass's A rows (2 tiles a step) and, in its first step, the next indices
-template <int F, int RT, int M1, int M2, int RES>
+// (HID: the activation step also stores the hidden layer, one store per column tile -- every lane, every time: the
+//  counts must be exact)
+template <int F, int RT, int M1, int M2, int RES, bool HID = false>
 struct Vis {
   static constexpr int of(int si) {
     using C = RCfg<F, RT>;
     if (si < C::KS) return RT * (((M1 != kNone && si < C::GS) ? C::NJ / C::GS : 0) + (RES == kResOther ? 2 : 0));
-    return RT * (2 + (si == C::KS ? (M1 == kIdx ? 1 : 0) + (M2 == kIdx ? 1 : 0) : 0));
+    return RT * (2 + (si == C::KS ? (M1 == kIdx ? 1 : 0) + (M2 == kIdx ? 1 : 0) + (HID ? C::NJ : 0) : 0));
   }
 };
 
-template <int F, int RT, int M1, int M2, bool SEG, int RES>
+// HID (the block's backward, gwen_mlp2_bwd_f32): the hidden layer is the PRODUCT (acc + b1) * G1[row] instead of
+// act(acc + G1 + b1), and it is stored as well (`hid`, rows padded to whole passes: the stores are unconditional) --
+//     g_pre1 = (ge W2 + T[dst]) * act'(pre1)  ->  hid ;   g_e = ge + g_pre1 We  ->  out
+// with A = res = ge, "W1" = W2^T, G1 = act'(pre1) row for row, G2 = T gathered by target, "W2" = We^T.
+template <int F, int RT, int M1, int M2, bool SEG, int RES, bool HID = false>
 __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k_mlp2r(
     const float *__restrict__ A, const char *__restrict__ img, const float *__restrict__ W1f,
     const float *__restrict__ W2f, const float *__restrict__ G1,
@@ -133,7 +139,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
     const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ res,
     float *__restrict__ out, int32_t R, int act, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ tile_row, int32_t n_tiles, float *__restrict__ agg, int mean,
-    uint32_t ldb1, uint32_t ldb2) {
+    uint32_t ldb1, uint32_t ldb2, float *__restrict__ hid = nullptr) {
   using C = RCfg<F, RT>;
   constexpr int NR = RT * C::NJ;                                     // float4 registers per set
   __shared__ __attribute__((aligned(1024))) char lds[C::lds_bytes];
@@ -255,7 +261,7 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
     dma(1, 1);
   }
 
-  using V = Vis<F, RT, M1, M2, RES>;
+  using V = Vis<F, RT, M1, M2, RES, HID>;
 
   bool last_pass = false;
   // One pass.  E: this pass's A rows (later the residual).  H: pre-loaded with the G2 rows (or zero) -- the first
@@ -333,8 +339,15 @@ __global__ __launch_bounds__((RCfg<F, RT>::NW * 64), (RCfg<F, RT>::MINW)) void k
 #pragma unroll
           for (int j = 0; j < C::NJ; ++j) {
             float4_t v = H[rt * C::NJ + j] + *reinterpret_cast<const float4_t *>(bl + col(j));
-            if constexpr (M1 != kNone) v += rc[rt * C::NJ + j];
-            H[rt * C::NJ + j] = activate(v, act);
+            if constexpr (HID) {
+              v = v * rc[rt * C::NJ + j];
+              H[rt * C::NJ + j] = v;
+              // (every lane stores: rows past the launch's last row land in the buffer's padding)
+              *reinterpret_cast<float4_t *>(hid + pass_off + (int64_t)prow(rt) * F + col(j)) = v;
+            } else {
+              if constexpr (M1 != kNone) v += rc[rt * C::NJ + j];
+              H[rt * C::NJ + j] = activate(v, act);
+            }
             rc[rt * C::NJ + j] = *reinterpret_cast<const float4_t *>(bl + F + col(j));
           }
       }
@@ -583,9 +596,44 @@ int launch_rows(const float *A, const float *W1, const float *G1, const int32_t 
   return GWEN_OK;
 }
 
+// the block's edge-level backward (see k_mlp2r, HID): hid = (ge W2t^T + T[dst]) * d1 ; out = ge + hid Wet^T
+template <int F>
+int launch_rows_bwd(const float *ge, const float *W2t, const float *d1, const float *T, const int32_t *dst,
+                    const float *Wet, float *hid, float *out, int64_t R, void *workspace, uint32_t ldbT, hipStream_t st) {
+  using C = RCfg<F, K6R_RT>;
+  bf16x8 *img = reinterpret_cast<bf16x8 *>(workspace);
+  if constexpr (!C::RESIDENT) {
+    k_split_wr<F><<<dim3(C::NJ * C::KS, 2), 64, 0, st>>>(W2t, Wet, img);
+    GWEN_LAUNCH_CHECK();
+  }
+  const int64_t tiles = (R + C::ROWS - 1) / C::ROWS;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    GWEN_HIP_CHECK(hipGetDevice(&dev));
+    GWEN_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = n < 8 ? 8 : n;
+  }
+  int64_t blocks = (int64_t)cus * (C::RESIDENT ? 2 : 1);
+  if (blocks > tiles) blocks = tiles;
+  k_mlp2r<F, K6R_RT, kSelf, kIdx, false, kResA, true><<<(unsigned)blocks, C::NW * 64, 0, st>>>(
+      ge, reinterpret_cast<const char *>(img), W2t, Wet, d1, nullptr, T, dst, nullptr, nullptr, ge, out, (int32_t)R,
+      GWEN_ACT_NONE, nullptr, nullptr, (int32_t)tiles, nullptr, 0, (uint32_t)(F * 4), ldbT, hid);
+  GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
 }  // namespace
 
 int gwen_mlp2_rows_f() { return RCfg<256, K6R_RT>::ROWS; }   // the same at every width this kernel takes
+
+int gwen_mlp2_rows_bwd_launch(int F, const float *ge, const float *W2t, const float *d1, const float *T,
+                              const int32_t *dst, const float *Wet, float *hid, float *out, int64_t R, void *workspace,
+                              uint32_t ldbT, hipStream_t st) {
+  if (F == 64) return launch_rows_bwd<64>(ge, W2t, d1, T, dst, Wet, hid, out, R, workspace, ldbT, st);
+  if (F == 256) return launch_rows_bwd<256>(ge, W2t, d1, T, dst, Wet, hid, out, R, workspace, ldbT, st);
+  return GWEN_EINVAL;
+}
 
 // interact.hip's dispatch for F = 256 (pointers validated there); m1 / m2 as interact.hip's kNone / kSelf / kIdx
 int gwen_mlp2_rows_launch(int F, int m1, int m2, const float *A, const float *W1, const float *G1, const int32_t *idx1,

@@ -306,6 +306,23 @@ def _ew(op: int, a: Tensor, b: Tensor) -> Tensor:
     return a
 
 
+def _edge_backward(ge: Tensor, w2t: Tensor, d1: Tensor, t: Tensor, dst: Tensor, wet: Tensor) -> Tuple[Tensor, Tensor]:
+    """gwen_mlp2_bwd_f32: (g_pre1, g_e) = ((ge W2 + T[dst]) * d1, ge + g_pre1 We) in one launch of K6's kernel."""
+    rows, f = ge.shape
+    L = _lib.lib()
+    dev = ge.device
+    padded = int(L.gwen_mlp2_bwd_rows(rows))
+    g_pre1 = torch.empty(padded, f, dtype=torch.float32, device=dev)        # whole passes: the kernel stores every lane
+    g_e = torch.empty_like(ge)
+    nws = int(L.gwen_mlp2_workspace_bytes(f))
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws > 0 else None
+    with torch.cuda.device(dev):
+        rc = L.gwen_mlp2_bwd_f32(_ptr(ge), _ptr(w2t), _ptr(d1), _ptr(t), _ptr(dst), t.size(0), t.stride(0), _ptr(wet),
+                                 _ptr(g_pre1), _ptr(g_e), rows, f, _ptr(ws), nws, _stream(dev))
+    _lib.check(rc, "gwen_mlp2_bwd_f32")
+    return g_pre1[:rows], g_e
+
+
 def _segsum(seg: Tuple[Tensor, Tensor, Tensor], h: Tensor, rows: int) -> Tensor:
     """K2 over an edge-position CSR (``EdgeGraph.segments``): out[i] = sum_s val[s] h[col[s]] in stored order."""
     rowptr, col, val = seg
@@ -384,6 +401,35 @@ class _InteractionNetFunction(torch.autograd.Function):
             g_xd = _ew(_lib.EW_ADD, lin(g_pre3, tr(wx_)), gx)
             del g_pre3, agg
             # ---- messages and edge MLP ----------------------------------------------------------------------------
+            if has_ge and _lib.lib().gwen_mlp2_bwd_supported(f):
+                # ONE launch of K6's kernel for the edge-level half (round 4): by linearity g_m W2 = ge W2 + T[dst] with
+                # T = (g_agg / degree) W2 per node, so the message gradient g_m = ge + g_agg[dst] is never formed --
+                # its two uses split the same way: g_m^T h1 = ge^T h1 + g_agg_s^T (sum of h1 over a target's edges),
+                # column sums of g_m = column sums of ge + sum_d degree_d g_agg_s[d]
+                g_agg_s = g_agg * g.inv_degree().view(-1, 1) if mean else g_agg
+                g_pre1, g_e = _edge_backward(ge, tr(w2), d1, lin(g_agg_s, tr(w2)), g.dst, tr(we))
+                del d1
+                hagg = _segsum(g.segments("dst"), h1, n_dst)
+                deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float32).view(-1, 1)
+                g_b2 = ops.grad_bias(ge) + (g_agg_s * deg).sum(0)
+                g_w2 = ops.grad_weight(ge, h1, _BWD_CONTRACT) + ops.grad_weight(g_agg_s, hagg, _BWD_CONTRACT)
+                del h1, hagg, g_agg, g_agg_s
+                big_d = _segsum(g.segments("dst"), g_pre1, n_dst)
+                g_b1 = ops.grad_bias(big_d)
+                big_s = _segsum(g.segments("src"), g_pre1, n_src)
+                g_w1 = torch.cat([ops.grad_weight(g_pre1, e, _BWD_CONTRACT), ops.grad_weight(big_s, x_src, _BWD_CONTRACT),
+                                  ops.grad_weight(big_d, x_dst, _BWD_CONTRACT)], dim=1)
+                del g_pre1
+                g_xs = lin(big_s, tr(ws_))
+                g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, tr(wd_)))
+                if same:
+                    g_xd = _ew(_lib.EW_ADD, g_xd, g_xs)
+                    g_xs = None
+                need = ctx.needs_input_grad
+                pick = lambda k, t: t if need[k] else None                                  # noqa: E731
+                return (None, None, None, None, pick(4, g_xs), pick(5, g_xd), pick(6, g_e), pick(7, g_w1),
+                        pick(8, g_b1), pick(9, g_w2), pick(10, g_b2), pick(11, g_w3), pick(12, g_b3), pick(13, g_w4),
+                        pick(14, g_b4))
             g_m = _gather_add(ge, g_agg, g.dst, g.inv_degree() if mean else None)
             g_b2, g_w2 = ops.grad_bias(g_m), ops.grad_weight(g_m, h1, _BWD_CONTRACT)
             g_pre1 = _ew(_lib.EW_MUL, lin(g_m, tr(w2)), d1)

@@ -502,6 +502,14 @@ int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_
  *                        h may alias a).  a, h, dact: [rows, F] contiguous, F % 4 == 0.
  *   gwen_gather_add_f32: out[r] = (a ? a[r] : 0) + t[idx[r]] * (scale ? scale[idx[r]] : 1)   t: [*, F] contiguous.
  *   gwen_ew_f32:         out = a * b (GWEN_EW_MUL) or a + b (GWEN_EW_ADD), n % 4 == 0; out may alias a or b.
+ *   gwen_mlp2_bwd_f32 (round 4): the edge-level half of the backward as ONE launch of K6's row-stationary kernel, at
+ *                        64 and 256 channels (gwen_mlp2_bwd_supported):
+ *                            g_pre1[r] = (ge[r] W2 + T[dst[r]]) * d1[r]        g_e[r] = ge[r] + g_pre1[r] We
+ *                        with T = (g_agg, scaled by 1 / degree for the mean) W2 computed per NODE, so that the message
+ *                        gradient ge + g_agg[dst] is never formed; W2t = W2^T, Wet = We^T ([F, F] row-major: row =
+ *                        output column); d1 = act'(pre1) [R, F]; T [T_rows, F] with row stride ldT.  g_pre1 has
+ *                        gwen_mlp2_bwd_rows(R) rows (R rounded up to whole passes: the kernel stores every lane), g_e
+ *                        [R, F] may be ge itself.  workspace as gwen_mlp2_f32.  3xbf16 contractions, as K6.
  * ------------------------------------------------------------------------------------------- */
 #define GWEN_EW_MUL 0
 #define GWEN_EW_ADD 1
@@ -511,6 +519,11 @@ int gwen_act_pair_f32(const float *a, const float *g1, const int32_t *idx1, int6
 int gwen_gather_add_f32(const float *a, const float *t, const int32_t *idx, const float *scale, float *out,
                         int64_t rows, int64_t F, gwen_stream_t stream);
 int gwen_ew_f32(int op, const float *a, const float *b, float *out, int64_t n, gwen_stream_t stream);
+int gwen_mlp2_bwd_supported(int64_t F);
+int64_t gwen_mlp2_bwd_rows(int64_t R);
+int gwen_mlp2_bwd_f32(const float *ge, const float *W2t, const float *d1, const float *T, const int32_t *dst,
+                      int64_t T_rows, int64_t ldT, const float *Wet, float *g_pre1, float *g_e, int64_t R, int64_t F,
+                      void *workspace, size_t workspace_bytes, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked L1 loss, value and gradient in one pass -- the reference's training objective
