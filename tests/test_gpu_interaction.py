@@ -311,11 +311,16 @@ def test_interaction_block_on_random_bipartite_graphs(ga, seed):
 
 
 @pytest.mark.parametrize("F,act,aggr,bip", [(32, "silu", "sum", False), (64, "relu", "mean", True),
-                                           (128, "silu", "sum", True), (64, "none", "sum", False)])
+                                           (128, "silu", "sum", True), (64, "none", "sum", False),
+                                           (64, "silu", "sum", True), (256, "silu", "sum", False),
+                                           (256, "silu", "mean", True), (256, "none", "sum", True)])
 def test_interaction_block_backward_vs_oracle_autograd(ga, F, act, aggr, bip):
     """Training through a block (forward on K6, backward assembled from atomic-free launches of libgwen_hip.so:
-    csrc/interact_bwd.hip + K2 / K3 / the gradient reductions): every gradient -- x_src, x_dst, e, the 8
-    parameters -- against torch autograd on the fp64 CPU oracle at 1e-4, and two backward runs bitwise equal."""
+    csrc/interact_bwd.hip + K2 / K3 / the gradient reductions; at 64 and 256 channels the edge-level half is ONE launch
+    of the row-stationary kernel, gwen_mlp2_bwd_f32 -- at 256 with the weight ring and its hand-counted waits -- and the
+    wide weight gradients run on the split contractions): every gradient -- x_src, x_dst, e, the 8 parameters -- against
+    torch autograd on the fp64 CPU oracle at 1e-4, and two backward runs bitwise equal.  Edge counts are several passes
+    of 128 rows plus a ragged tail (the kernel stores whole passes of the hidden layer into a padded buffer)."""
     from gwen_amd.interaction import InteractionNet, interaction_graph
     from oracle import interaction_oracle as IO
     rng = np.random.default_rng(77 + F)

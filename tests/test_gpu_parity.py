@@ -638,6 +638,25 @@ def test_linear_autograd_vs_fp64(ga, contract, tol, rows, fin, fout, relu, use_b
         assert rel_err(bd.grad, b64.grad) <= tol
 
 
+@pytest.mark.parametrize("rows,fout,fin", [(5000, 128, 128), (70001, 256, 256), (3000, 256, 64), (2047, 64, 256),
+                                           (2049, 128, 256), (1, 256, 256), (4096, 192, 128), (300, 64, 64), (777, 20, 48)])
+def test_grad_weight_every_contraction_vs_fp64(ga, rows, fout, fin):
+    """ops.grad_weight = g^T x on every contraction against fp64: widths the split kernels take (multiples of 64 from
+    128 x 128: 64 x 64 tiles, LDS-staged, chunks of 2 048 rows -- one row, one row short of / past a chunk, a 192-wide
+    side) and widths that stay on the fp32-input MFMA whatever is asked; rows of very different magnitude; two runs
+    bitwise equal (fixed summation order)."""
+    from gwen_amd import ops
+    gen = torch.Generator().manual_seed(SEED + rows)
+    g = torch.randn(rows, fout, generator=gen) * torch.exp2(torch.randint(-6, 7, (rows, 1), generator=gen).float())
+    x = torch.randn(rows, fin, generator=gen)
+    want = g.double().t() @ x.double()
+    gd, xd = g.to(DEV), x.to(DEV)
+    for contract, tol in ((None, 2e-6), ("fp32", 2e-6), ("bf16x6", 4e-6), ("f16x3", 4e-6), ("3xbf16", 3e-5)):
+        got = ops.grad_weight(gd, xd, contract)
+        assert rel_err(got, want) <= tol, (contract, rel_err(got, want))
+        assert torch.equal(got, ops.grad_weight(gd, xd, contract)), contract
+
+
 def test_stack_backward_without_input_grad_and_determinism(ga):
     m = ga.geodesic_mesh(9, reorder="hilbert")
     ei = torch.from_numpy(m.edge_index).to(DEV)
