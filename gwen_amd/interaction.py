@@ -401,18 +401,24 @@ class _InteractionNetFunction(torch.autograd.Function):
             g_xd = _ew(_lib.EW_ADD, lin(g_pre3, tr(wx_)), gx)
             del g_pre3, agg
             # ---- messages and edge MLP ----------------------------------------------------------------------------
-            if has_ge and _lib.lib().gwen_mlp2_bwd_supported(f):
+            if _lib.lib().gwen_mlp2_bwd_supported(f):
                 # ONE launch of K6's kernel for the edge-level half (round 4): by linearity g_m W2 = ge W2 + T[dst] with
                 # T = (g_agg / degree) W2 per node, so the message gradient g_m = ge + g_agg[dst] is never formed --
                 # its two uses split the same way: g_m^T h1 = ge^T h1 + g_agg_s^T (sum of h1 over a target's edges),
                 # column sums of g_m = column sums of ge + sum_d degree_d g_agg_s[d]
+                # (a block without an edge output -- the encoder / decoder blocks -- has ge = 0: the same launch on a
+                #  zero array still replaces four launches and nine passes, and ge's own gradient terms drop out)
                 g_agg_s = g_agg * g.inv_degree().view(-1, 1) if mean else g_agg
-                g_pre1, g_e = _edge_backward(ge, tr(w2), d1, lin(g_agg_s, tr(w2)), g.dst, tr(we))
+                g_pre1, g_e = _edge_backward(ge if has_ge else torch.zeros_like(e), tr(w2), d1,
+                                             lin(g_agg_s, tr(w2)), g.dst, tr(we))
                 del d1
                 hagg = _segsum(g.segments("dst"), h1, n_dst)
                 deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float32).view(-1, 1)
-                g_b2 = ops.grad_bias(ge) + (g_agg_s * deg).sum(0)
-                g_w2 = ops.grad_weight(ge, h1, _BWD_CONTRACT) + ops.grad_weight(g_agg_s, hagg, _BWD_CONTRACT)
+                g_b2 = (g_agg_s * deg).sum(0)
+                g_w2 = ops.grad_weight(g_agg_s, hagg, _BWD_CONTRACT)
+                if has_ge:
+                    g_b2 = g_b2 + ops.grad_bias(ge)
+                    g_w2 = g_w2 + ops.grad_weight(ge, h1, _BWD_CONTRACT)
                 del h1, hagg, g_agg, g_agg_s
                 big_d = _segsum(g.segments("dst"), g_pre1, n_dst)
                 g_b1 = ops.grad_bias(big_d)

@@ -4,6 +4,7 @@ H=${1:-64}
 out=$GRAFT_REPO_ROOT/gpurun_out/inet_train_prof_$H
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
+export INET_SKIP_OLD=1       # only the product's step: no torch-recompute comparison, no graph capture in the trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -- python3 $GRAFT_REPO_ROOT/tools/inet_train_bench.py $H > $out/t.log 2>&1
 python3 - <<PY
 import csv, glob

@@ -109,13 +109,16 @@ def graphed_step_ms():
 
 
 try:
-    t_graph = round(graphed_step_ms(), 3)
+    t_graph = float("nan") if os.environ.get("INET_SKIP_OLD") == "1" else round(graphed_step_ms(), 3)
 except Exception as exc:                                # capture is best effort: say why it did not work
     t_graph = f"not captured: {type(exc).__name__}: {str(exc)[:200]}"
-keep = I._InteractionNetFunction.backward
-I._InteractionNetFunction.backward = staticmethod(torch_backward)
-t_old = timed()
-I._InteractionNetFunction.backward = keep
+if os.environ.get("INET_SKIP_OLD") == "1":           # (profiling runs: only the product's kernels in the trace)
+    t_old = float("nan")
+else:
+    keep = I._InteractionNetFunction.backward
+    I._InteractionNetFunction.backward = staticmethod(torch_backward)
+    t_old = timed()
+    I._InteractionNetFunction.backward = keep
 with torch.no_grad():
     model.eval()
     for _ in range(3):
