@@ -12,7 +12,17 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kChunkRows = 256;    // rows reduced by one block before the cross-chunk stage
-constexpr int kWideChunkRows = 2048;   // ... by one block of the split kernel (k_grad_w_split)
+constexpr int kWideChunkRows = 2048;   // ... by one block of the split kernels at 128 x 128 and wider
+constexpr int kNarrowChunkRows = 512;  // ... at 64 x 64 .. 64 x 128 (one or two waves per block: more blocks to fill the chip)
+// rows per block: as many as keep ~2 048 blocks in the launch (a node-sized gradient -- 100 000 rows -- would otherwise be
+// 49 blocks at 256 channels), whole 16-row steps, between 256 and the width's maximum
+inline int split_chunk_rows(int64_t rows, int64_t Fin, int64_t Fout) {
+  const int64_t cap = Fin * Fout >= 128 * 128 ? kWideChunkRows : kNarrowChunkRows;
+  const int64_t tiles = ((Fin + 127) / 128) * ((Fout + 127) / 128);
+  int64_t cr = (rows * tiles / 2048 + 15) / 16 * 16;
+  cr = cr < kChunkRows ? kChunkRows : (cr > cap ? cap : cr);     // (never more slots than gwen_gcn_grad_chunks(rows): the
+  return (int)cr;                                                //  workspaces are sized by that)
+}
 constexpr int kU = 8;              // independent loads in flight per thread in every reduction loop
 
 // One wave = one 32x32 tile of grad_W (rows = output channel, cols = input channel) over one chunk
@@ -81,14 +91,15 @@ __device__ inline f32x16 mma32_split(const gwen::bf16x8 (&a)[NS], const gwen::bf
 template <int NS>
 __global__ __launch_bounds__(kThreads) void k_grad_w_split(const float *__restrict__ g, const float *__restrict__ x,
                                                            float *__restrict__ dst, int64_t rows, int Fin, int Fout,
-                                                           int64_t ldg, int64_t ldx, int tiles_i, int ntiles) {
+                                                           int64_t ldg, int64_t ldx, int tiles_i, int ntiles,
+                                                           int chunk_rows) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.y * 4 + wave;
   if (tile >= ntiles) return;
   const int o0 = (tile / tiles_i) * 64, i0 = (tile % tiles_i) * 64;
-  const int64_t r0 = (int64_t)blockIdx.x * kWideChunkRows;
-  const int64_t r1 = (r0 + kWideChunkRows < rows) ? r0 + kWideChunkRows : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+  const int64_t r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
   const float *gp = g + o0 + li, *xp = x + i0 + li;
   f32x16 acc[2][2] = {};
   // this lane's 8 rows of a 16-row step: r + 8 lh .. + 7 (the k index of the MFMA's 8 values per lane), clamped to the
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void k_grad_w_split(const float *__restri
 template <int NS, int BO, int BI>
 __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
     const float *__restrict__ g, const float *__restrict__ x, float *__restrict__ dst, int64_t rows, int Fin, int Fout,
-    int64_t ldg, int64_t ldx, int tiles_i) {
+    int64_t ldg, int64_t ldx, int tiles_i, int chunk_rows) {
   constexpr int NWB = (BO / 64) * (BI / 64);                 // waves per block
   constexpr int kStepBytes = 16 * (BO + BI) * 4;             // one step's tiles: g [16][BO] | x [16][BI]
   constexpr int PG = BO / 16, NPC = (BO + BI) / 16, PPW = NPC / NWB;     // 1-KiB pieces: of g, in all, per wave
@@ -156,8 +167,8 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
   const int li = lane & 31, lh = lane >> 5;
   const int wo = wave / (BI / 64), wi = wave % (BI / 64);
   const int o0 = ((int)blockIdx.y / tiles_i) * BO, i0 = ((int)blockIdx.y % tiles_i) * BI;
-  const int64_t r0 = (int64_t)blockIdx.x * kWideChunkRows;
-  const int64_t r1 = (r0 + kWideChunkRows < rows) ? r0 + kWideChunkRows : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+  const int64_t r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
   const char *gb = uniform_ptr(g + r0 * ldg + o0), *xb = uniform_ptr(x + r0 * ldx + i0);
   const int nsteps = (int)((r1 - r0 + 15) / 16), nrows = (int)(r1 - r0);
   // step st's tiles -> buffer buf: piece p of g holds 1024 / (4 BO) rows of BO floats (lane l: 16 B at column 4 (l % (BO / 4))
@@ -213,8 +224,7 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
 
 // the split kernel takes a weight gradient when its widths allow and the contraction is a bf16 split
 inline bool wide_grad(int64_t Fin, int64_t Fout, int contract) {
-  return (contract == GWEN_CONTRACT_BF16X3 || contract == GWEN_CONTRACT_BF16X6) && Fin % 64 == 0 && Fout % 64 == 0 &&
-         Fin * Fout >= 128 * 128;
+  return (contract == GWEN_CONTRACT_BF16X3 || contract == GWEN_CONTRACT_BF16X6) && Fin % 64 == 0 && Fout % 64 == 0;
 }
 
 // dst[j] = sum over chunks of partial[c][j], in a fixed order: 16 phases (phase p adds chunks p, p+16,
@@ -285,7 +295,8 @@ __global__ void k_relu_bwd(const float *__restrict__ y, const float *__restrict_
 inline int64_t nchunks_for(int64_t rows) { return rows > 0 ? (rows + kChunkRows - 1) / kChunkRows : 1; }
 inline int64_t nchunks_w(int64_t rows, int64_t Fin, int64_t Fout, int contract) {     // partial slots of a weight gradient
   if (!wide_grad(Fin, Fout, contract)) return nchunks_for(rows);
-  return rows > 0 ? (rows + kWideChunkRows - 1) / kWideChunkRows : 1;
+  const int64_t cr = split_chunk_rows(rows, Fin, Fout);
+  return rows > 0 ? (rows + cr - 1) / cr : 1;
 }
 
 // stage 1 of grad_W into `dst` ([slots, Fout * Fin]; slots = nchunks_w)
@@ -293,16 +304,16 @@ int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int6
                   int64_t ldx, int contract, hipStream_t st) {
   if (wide_grad(Fin, Fout, contract)) {
     const int64_t nc = nchunks_w(rows, Fin, Fout, contract);
-    if (nc > 0x7fffffffLL || ldg * 4 * kWideChunkRows >= (int64_t(1) << 31) || ldx * 4 * kWideChunkRows >= (int64_t(1) << 31))
-      return GWEN_ERANGE;
+    const int cr = split_chunk_rows(rows, Fin, Fout);
+    if (nc > 0x7fffffffLL || ldg * 4 * cr >= (int64_t(1) << 31) || ldx * 4 * cr >= (int64_t(1) << 31)) return GWEN_ERANGE;
     if (!gwen_aligned(g, 16) || !gwen_aligned(x, 16) || ldg % 4 || ldx % 4) {     // (the DMA moves 16-byte pieces)
       const int tiles_i = (int)(Fin / 64), ntiles = (int)(Fin / 64 * (Fout / 64));
       if ((ntiles + 3) / 4 > 65535) return GWEN_ERANGE;
       dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
       if (contract == GWEN_CONTRACT_BF16X6)
-        k_grad_w_split<3><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+        k_grad_w_split<3><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles, cr);
       else
-        k_grad_w_split<2><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles);
+        k_grad_w_split<2><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, ntiles, cr);
       GWEN_LAUNCH_CHECK();
       return GWEN_OK;
     }
@@ -312,7 +323,7 @@ int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int6
     const int64_t nt = (int64_t)ti * (Fout / BO_);                                                                 \
     if (nt > 65535) return GWEN_ERANGE;                                                                            \
     k_grad_w_lds<NS_, BO_, BI_><<<dim3((unsigned)nc, (unsigned)nt), (BO_ / 64) * (BI_ / 64) * 64, 0, st>>>(        \
-        g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, ti);                                                       \
+        g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, ti, cr);                                                   \
   } while (0)
     const bool o128 = Fout % 128 == 0, i128 = Fin % 128 == 0, x6 = contract == GWEN_CONTRACT_BF16X6;
     if (o128 && i128) { if (x6) GWEN_GW(3, 128, 128); else GWEN_GW(2, 128, 128); }
