@@ -377,8 +377,8 @@ int gwen_event_elapsed_ms(void *start, void *stop, float *ms /* host out */);
  *   grad_W[Fout,Fin] = g^T @ x   (g [rows,Fout], x [rows,Fin]); deterministic two-stage reduce.  contract: the
  *                      contraction of the layer the gradient belongs to -- GWEN_CONTRACT_F32: fp32-input MFMA (exact
  *                      fp32 products); _BF16X3 / _BF16X6 (_F16X3 = _BF16X6 here): the split contractions on 64 x 64
- *                      tiles of grad_W where Fin, Fout are multiples of 64 and Fin * Fout >= 128^2 (at 256 channels
- *                      3 - 6 x the fp32 MFMA's rate), the fp32 MFMA elsewhere.
+ *                      tiles of grad_W, operands staged through LDS, where Fin and Fout are multiples of 64 (at 256
+ *                      channels 2.7 - 3.7 x the fp32 MFMA's rate), the fp32 MFMA elsewhere.
  *   grad_b[F]        = column sums of g.
  *   relu mask        : g *= (y > 0).
  * partial: fp32 workspace of gwen_gcn_grad_workspace_floats(rows, Fin, Fout) elements.
