@@ -1,8 +1,10 @@
 #!/bin/bash
-out=$GRAFT_REPO_ROOT/gpurun_out/train_prof
+# rocprofv3 kernel stats of a GCN training step:  tools/experiments/train_prof.sh [mesh|ref] [more train_bench.py args]
+which=${1:-mesh}; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/train_prof_$which
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -- python3 $GRAFT_REPO_ROOT/tools/train_bench.py mesh > $out/t.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -- python3 $GRAFT_REPO_ROOT/tools/train_bench.py $which "$@" > $out/t.log 2>&1
 python3 - <<PY
 import csv, glob
 for f in glob.glob("$out/t/**/*kernel_stats.csv", recursive=True):
