@@ -12,16 +12,32 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kChunkRows = 256;    // rows reduced by one block before the cross-chunk stage
-constexpr int kWideChunkRows = 2048;   // ... by one block of the split kernels at 128 x 128 and wider
+constexpr int kWideChunkRows = 4096;   // ... at most, by one 128 x 128 block of the split kernels
+constexpr int kWideBlocksPerChip = 768;    // 128 x 128 blocks resident on 256 CUs (3 per CU: 132 registers a lane;
+                                           // forced to 4 per CU the kernel is no faster: it is bound by its VALU + MFMA work)
 constexpr int kNarrowChunkRows = 512;  // ... at 64 x 64 .. 64 x 128 (one or two waves per block: more blocks to fill the chip)
-// rows per block: as many as keep ~2 048 blocks in the launch (a node-sized gradient -- 100 000 rows -- would otherwise be
-// 49 blocks at 256 channels), whole 16-row steps, between 256 and the width's maximum
+// rows per block of the split kernels.  128 x 128 blocks (4 waves, 32 KiB of LDS, 3 waves per SIMD by registers: the 256
+// CUs hold 768 of them at once) are launched in whole ROUNDS of the chip, because a launch of 2.04 rounds takes three: at
+// 256 x 256 on 100 000 rows the ~2 048-block rule below gave 1 564 blocks on 768 places (87 us; 190 chunks in ONE round: 65,
+// and half the partial sums to write and to reduce -- 119 -> 82 us with the finish; 600 000 rows 509 -> 385).  The fewest
+// rounds that keep a chunk under the cap.  The narrower blocks (1 - 2 waves) keep ~2 048 blocks per launch (a node-sized
+// gradient -- 100 000 rows -- would otherwise be 49 blocks): measured better there than whole rounds (600 000 x 64 x 64:
+// 72 vs 84 us).  Whole 16-row steps; never under kChunkRows rows (the workspaces are sized by
+// gwen_gcn_grad_chunks(rows) = rows / kChunkRows slots).
 inline int split_chunk_rows(int64_t rows, int64_t Fin, int64_t Fout) {
-  const int64_t cap = Fin * Fout >= 128 * 128 ? kWideChunkRows : kNarrowChunkRows;
-  const int64_t tiles = ((Fin + 127) / 128) * ((Fout + 127) / 128);
-  int64_t cr = (rows * tiles / 2048 + 15) / 16 * 16;
-  cr = cr < kChunkRows ? kChunkRows : (cr > cap ? cap : cr);     // (never more slots than gwen_gcn_grad_chunks(rows): the
-  return (int)cr;                                                //  workspaces are sized by that)
+  int64_t cr;
+  if (Fin % 128 == 0 && Fout % 128 == 0) {
+    const int64_t tiles = (Fin / 128) * (Fout / 128);
+    const int64_t per_round = kWideBlocksPerChip / tiles > 0 ? kWideBlocksPerChip / tiles : 1;       // chunks in one round
+    const int64_t rounds = (rows + kWideChunkRows * per_round - 1) / (kWideChunkRows * per_round);
+    const int64_t chunks = (rounds > 0 ? rounds : 1) * per_round;
+    cr = ((rows + chunks - 1) / chunks + 15) / 16 * 16;
+  } else {
+    const int64_t tiles = ((Fin + 127) / 128) * ((Fout + 127) / 128);
+    cr = (rows * tiles / 2048 + 15) / 16 * 16;
+    cr = cr > kNarrowChunkRows ? kNarrowChunkRows : cr;
+  }
+  return (int)(cr < kChunkRows ? kChunkRows : cr);
 }
 constexpr int kU = 8;              // independent loads in flight per thread in every reduction loop
 

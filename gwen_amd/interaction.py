@@ -392,11 +392,15 @@ class _InteractionNetFunction(torch.autograd.Function):
             h3, d3 = _act_pair(lin(agg, wa), act, q)
             del pall, q
             # ---- node MLP -----------------------------------------------------------------------------------------
-            g_b4, g_w4 = ops.grad_bias(gx), ops.grad_weight(gx, h3, _BWD_CONTRACT)
+            # (every weight / bias gradient: stage 1 launched where its operands are live, the fixed-order finishes of
+            #  all of them in ONE launch at the end -- ops.GradBatch)
+            gb = ops.GradBatch()
+            gw = lambda a, b_: gb.grad_weight(a, b_, _BWD_CONTRACT)                          # noqa: E731
+            g_b4, g_w4 = gb.grad_bias(gx), gw(gx, h3)
             g_pre3 = _ew(_lib.EW_MUL, lin(gx, tr(w4)), d3)
             del h3, d3
-            g_b3 = ops.grad_bias(g_pre3)
-            g_w3 = torch.cat([ops.grad_weight(g_pre3, x_dst, _BWD_CONTRACT), ops.grad_weight(g_pre3, agg, _BWD_CONTRACT)], dim=1)
+            g_b3 = gb.grad_bias(g_pre3)
+            g_w3 = [gw(g_pre3, x_dst), gw(g_pre3, agg)]
             g_agg = lin(g_pre3, tr(wa))
             g_xd = _ew(_lib.EW_ADD, lin(g_pre3, tr(wx_)), gx)
             del g_pre3, agg
@@ -415,36 +419,38 @@ class _InteractionNetFunction(torch.autograd.Function):
                 hagg = _segsum(g.segments("dst"), h1, n_dst)
                 deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float32).view(-1, 1)
                 g_b2 = (g_agg_s * deg).sum(0)
-                g_w2 = ops.grad_weight(g_agg_s, hagg, _BWD_CONTRACT)
-                if has_ge:
-                    g_b2 = g_b2 + ops.grad_bias(ge)
-                    g_w2 = g_w2 + ops.grad_weight(ge, h1, _BWD_CONTRACT)
+                g_w2 = gw(g_agg_s, hagg)
+                g_b2e, g_w2e = (gb.grad_bias(ge), gw(ge, h1)) if has_ge else (None, None)
                 del h1, hagg, g_agg, g_agg_s
                 big_d = _segsum(g.segments("dst"), g_pre1, n_dst)
-                g_b1 = ops.grad_bias(big_d)
+                g_b1 = gb.grad_bias(big_d)
                 big_s = _segsum(g.segments("src"), g_pre1, n_src)
-                g_w1 = torch.cat([ops.grad_weight(g_pre1, e, _BWD_CONTRACT), ops.grad_weight(big_s, x_src, _BWD_CONTRACT),
-                                  ops.grad_weight(big_d, x_dst, _BWD_CONTRACT)], dim=1)
+                g_w1 = [gw(g_pre1, e), gw(big_s, x_src), gw(big_d, x_dst)]
                 del g_pre1
                 g_xs = lin(big_s, tr(ws_))
                 g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, tr(wd_)))
                 if same:
                     g_xd = _ew(_lib.EW_ADD, g_xd, g_xs)
                     g_xs = None
+                gb.finish()
+                g_w1, g_w3 = torch.cat(g_w1, dim=1), torch.cat(g_w3, dim=1)
+                if has_ge:
+                    g_b2, g_w2 = g_b2 + g_b2e, g_w2 + g_w2e
                 need = ctx.needs_input_grad
                 pick = lambda k, t: t if need[k] else None                                  # noqa: E731
                 return (None, None, None, None, pick(4, g_xs), pick(5, g_xd), pick(6, g_e), pick(7, g_w1),
                         pick(8, g_b1), pick(9, g_w2), pick(10, g_b2), pick(11, g_w3), pick(12, g_b3), pick(13, g_w4),
                         pick(14, g_b4))
             g_m = _gather_add(ge, g_agg, g.dst, g.inv_degree() if mean else None)
-            g_b2, g_w2 = ops.grad_bias(g_m), ops.grad_weight(g_m, h1, _BWD_CONTRACT)
+            g_b2, g_w2 = gb.grad_bias(g_m), gw(g_m, h1)
             g_pre1 = _ew(_lib.EW_MUL, lin(g_m, tr(w2)), d1)
             del g_m, h1, d1, g_agg
             big_d = _segsum(g.segments("dst"), g_pre1, n_dst)          # per target: sum over its in-edges
-            g_b1 = ops.grad_bias(big_d)                                # = column sums of g_pre1, over N_dst rows instead of E
+            g_b1 = gb.grad_bias(big_d)                                 # = column sums of g_pre1, over N_dst rows instead of E
             big_s = _segsum(g.segments("src"), g_pre1, n_src)          # per source: sum over its out-edges
-            g_w1 = torch.cat([ops.grad_weight(g_pre1, e, _BWD_CONTRACT), ops.grad_weight(big_s, x_src, _BWD_CONTRACT),
-                              ops.grad_weight(big_d, x_dst, _BWD_CONTRACT)], dim=1)
+            g_w1 = [gw(g_pre1, e), gw(big_s, x_src), gw(big_d, x_dst)]
+            gb.finish()
+            g_w1, g_w3 = torch.cat(g_w1, dim=1), torch.cat(g_w3, dim=1)
             g_e = lin(g_pre1, tr(we))
             if has_ge:
                 g_e = _ew(_lib.EW_ADD, g_e, ge)

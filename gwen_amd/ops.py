@@ -5,6 +5,7 @@ arithmetic step of the layer runs in libgwen_hip.so.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Optional
 
@@ -325,6 +326,74 @@ def grad_bias(g: Tensor) -> Tensor:
                                                _stream(g.device))
     _lib.check(rc, "gwen_gcn_grad_bias_f32")
     return out
+
+
+class _ReduceTask(ctypes.Structure):          # gwen_reduce_task (include/gwen_hip.h)
+    _fields_ = [("partial", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("count", ctypes.c_int64),
+                ("nchunks", ctypes.c_int64)]
+
+
+class GradBatch:
+    """Many grad_weight / grad_bias reductions whose fixed-order finishes share ONE launch
+    (gwen_reduce_chunks_batched, up to 32 per launch) instead of one each: stage 1 of every reduction is launched
+    at once, the returned tensors are complete after ``finish()``.  Same chunking and summation order per reduction
+    whatever else is in the batch (deterministic, run to run bitwise)."""
+
+    def __init__(self) -> None:
+        self._tasks: list = []
+        self._keep: list = []
+        self._dev = None
+
+    def _add(self, partial: Tensor, out: Tensor, count: int, nch: int) -> None:
+        self._tasks.append((partial.data_ptr(), out.data_ptr(), count, nch))
+        self._keep += [partial, out]
+
+    def grad_weight(self, g: Tensor, x: Tensor, contract: Optional[str] = None) -> Tensor:
+        g = g.contiguous(); x = x.contiguous()
+        fout, fin = g.size(-1), x.size(-1)
+        rows = math.prod(g.shape[:-1])
+        dev = self._dev = g.device
+        out = torch.empty(fout, fin, dtype=torch.float32, device=dev)
+        if rows == 0:
+            return out.zero_()
+        code = _contract_code(contract)
+        nch = int(_lib.lib().gwen_gcn_grad_weight_chunks(rows, fin, fout, code))
+        dst = out if nch == 1 else torch.empty(nch * fout * fin, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gwen_gcn_grad_weight_partial_f32(_ptr(g), _ptr(x), _ptr(dst), rows, fin, fout, fout, fin,
+                                                             code, _stream(dev))
+        _lib.check(rc, "gwen_gcn_grad_weight_partial_f32")
+        if nch > 1:
+            self._add(dst, out, fout * fin, nch)
+        return out
+
+    def grad_bias(self, g: Tensor) -> Tensor:
+        g = g.contiguous()
+        f = g.size(-1)
+        rows = math.prod(g.shape[:-1])
+        dev = self._dev = g.device
+        out = torch.empty(f, dtype=torch.float32, device=dev)
+        if rows == 0:
+            return out.zero_()
+        nch = int(_lib.lib().gwen_gcn_grad_chunks(rows))
+        dst = out if nch == 1 else torch.empty(nch * f, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gwen_gcn_grad_bias_partial_f32(_ptr(g), _ptr(dst), rows, f, f, _stream(dev))
+        _lib.check(rc, "gwen_gcn_grad_bias_partial_f32")
+        if nch > 1:
+            self._add(dst, out, f, nch)
+        return out
+
+    def finish(self) -> None:
+        cap = 32                                             # GWEN_MAX_REDUCE_TASKS
+        for i in range(0, len(self._tasks), cap):
+            part = self._tasks[i:i + cap]
+            arr = (_ReduceTask * len(part))(*[_ReduceTask(*t) for t in part])
+            with torch.cuda.device(self._dev):
+                rc = _lib.lib().gwen_reduce_chunks_batched(ctypes.cast(arr, ctypes.c_void_p), len(part),
+                                                           _stream(self._dev))
+            _lib.check(rc, "gwen_reduce_chunks_batched")
+        self._tasks, self._keep = [], []
 
 
 def relu_backward(y: Tensor, g: Tensor) -> Tensor:

@@ -659,6 +659,39 @@ def test_grad_weight_every_contraction_vs_fp64(ga, rows, fout, fin):
         assert torch.equal(got, ops.grad_weight(gd, xd, contract)), contract
 
 
+def test_grad_batch_many_reductions_one_finish(ga):
+    """ops.GradBatch: 40 weight / bias reductions of mixed shape (more than one 32-task launch; one-chunk reductions
+    that finish in stage 1; an empty one) -- each against fp64, and bitwise the stand-alone ops.grad_weight /
+    ops.grad_bias of the same operands in spirit: the same chunking, so equal to 1e-6 and run to run bitwise."""
+    from gwen_amd import ops
+    gen = torch.Generator().manual_seed(SEED)
+    shapes = [(70001, 256, 256), (5000, 128, 128), (100, 64, 64), (2049, 128, 256), (777, 20, 48), (0, 64, 64),
+              (200000, 64, 64), (1, 256, 64)] * 3
+    ops_in = [(torch.randn(r, fo, generator=gen).to(DEV), torch.randn(r, fi, generator=gen).to(DEV))
+              for r, fo, fi in shapes[:8]] * 3
+    runs = []
+    for _ in range(2):
+        gb = ops.GradBatch()
+        outs = []
+        for k, (g, x) in enumerate(ops_in):
+            outs.append(gb.grad_weight(g, x, ("bf16x6", "f16x3", None)[k % 3]))
+            if k % 2 == 0 or k >= 8:
+                outs.append(gb.grad_bias(g))
+        gb.finish()
+        torch.cuda.synchronize()
+        runs.append(outs)
+    assert len(runs[0]) >= 40 and all(torch.equal(a, b) for a, b in zip(*runs))
+    it = iter(runs[0])
+    for k, (g, x) in enumerate(ops_in):
+        got = next(it)
+        assert rel_err(got, g.double().t() @ x.double()) <= 4e-6 if g.size(0) else not bool(got.any())
+        if g.size(0):
+            assert rel_err(got, ops.grad_weight(g, x, ("bf16x6", "f16x3", None)[k % 3])) <= 1e-6
+        if k % 2 == 0 or k >= 8:
+            gotb = next(it)
+            assert rel_err(gotb, g.double().sum(0)) <= 2e-6 if g.size(0) else not bool(gotb.any())
+
+
 def test_stack_backward_without_input_grad_and_determinism(ga):
     m = ga.geodesic_mesh(9, reorder="hilbert")
     ei = torch.from_numpy(m.edge_index).to(DEV)
