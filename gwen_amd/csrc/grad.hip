@@ -203,10 +203,13 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
   };
   f32x16 acc[2][2] = {};
   issue(0, 0);
-  for (int st = 0; st < nsteps; ++st) {
+  // one 16-row step; TAIL = the chunk's last step, the only one that can hold rows past the chunk (zeroed as they are
+  // read: the 16 compare + select pairs are not paid in the other steps)
+  auto step = [&](int st, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     wait_vm<0>();                                   // this wave's pieces of step st (issued a step ago) have landed
     __syncthreads();                                // ... everyone's; and everyone is done reading the other buffer
-    if (st + 1 < nsteps) issue(st + 1, (st + 1) & 1);
+    if constexpr (!TAIL) issue(st + 1, (st + 1) & 1);
     const float *lg = reinterpret_cast<const float *>(lds + (st & 1) * kStepBytes), *lx = lg + 16 * BO;
     gwen::bf16x8 ai[2][NS], bi[2][NS];
 #pragma unroll
@@ -215,7 +218,7 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float a = lg[(8 * lh + t) * BO + 64 * wo + 32 * s + li];
-        av[t] = st * 16 + 8 * lh + t < nrows ? a : 0.0f;
+        av[t] = (!TAIL || st * 16 + 8 * lh + t < nrows) ? a : 0.0f;
         bv[t] = lx[(8 * lh + t) * BI + 64 * wi + 32 * s + li];
       }
       gwen::split_images<8, NS>(av, ai[s]);
@@ -225,7 +228,9 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
     for (int so = 0; so < 2; ++so)
 #pragma unroll
       for (int si = 0; si < 2; ++si) acc[so][si] = mma32_split<NS>(ai[so], bi[si], acc[so][si]);
-  }
+  };
+  for (int st = 0; st + 1 < nsteps; ++st) step(st, std::false_type{});
+  step(nsteps - 1, std::true_type{});
   float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
 #pragma unroll
   for (int so = 0; so < 2; ++so)
