@@ -72,6 +72,12 @@ class EdgeGraph:
                 raise ValueError("segments: by in ('dst', 'src'); mean only by 'dst'")
         return self._seg[key]
 
+    def degree(self) -> Tensor:
+        """in-degree per target node, fp32 [num_dst, 1] (cached)."""
+        if "deg" not in self._seg:
+            self._seg["deg"] = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32).view(-1, 1).contiguous()
+        return self._seg["deg"]
+
     def inv_degree(self) -> Tensor:
         """1 / max(in-degree, 1) per target node, fp32 [num_dst] (mean aggregation)."""
         if "inv_deg" not in self._seg:
@@ -369,17 +375,18 @@ class _InteractionNetFunction(torch.autograd.Function):
         n_src, n_dst = g.num_src, g.num_dst
         with torch.no_grad():
             lin = lambda x, w, b=None: ops.linear(x, w, b, contract=_BWD_CONTRACT)          # noqa: E731
-            tr = lambda w: w.t().contiguous()                                               # noqa: E731
             x_src, x_dst, e = x_src.detach().contiguous(), x_dst.detach().contiguous(), e.detach().contiguous()
             gx = gx.contiguous()
             has_ge = bool(ctx.update_edges and ge is not None and ge.numel() > 0)
             ge = ge.contiguous() if has_ge else None
-            we, wa = w1[:, :f].contiguous(), w3[:, f:].contiguous()
-            ws_, wd_, wx_ = w1[:, f:2 * f].contiguous(), w1[:, 2 * f:].contiguous(), w3[:, :f].contiguous()
+            # every W^T the backward contracts with, from FOUR small copies (the row blocks of a transposed matrix are
+            # contiguous): w1 = [We | Ws | Wd], w3 = [Wx | Wa]  (thirteen slice / transpose copies a block before)
+            w1t, w3t, w2t, w4t = (w.t().contiguous() for w in (w1, w3, w2, w4))
+            wet, wst, wdt, wxt, wat = w1t[:f], w1t[f:2 * f], w1t[2 * f:], w3t[:f], w3t[f:]
             # ---- the two hidden layers again (the forward kept nothing) -----------------------------------------
             # the node-side projections as the forward makes them: ONE stacked launch [Ps | Pd | Q] when x_src is x_dst
             # (two when not); the kernels below read the column blocks through a row stride
-            _, _, wn, bn = net._weight_blocks()
+            we, wa, wn, bn = net._weight_blocks()
             if same:
                 pall = lin(x_dst, wn, bn)
                 ps, pd, q = pall[:, :f], pall[:, f:2 * f], pall[:, 2 * f:]
@@ -397,12 +404,12 @@ class _InteractionNetFunction(torch.autograd.Function):
             gb = ops.GradBatch()
             gw = lambda a, b_: gb.grad_weight(a, b_, _BWD_CONTRACT)                          # noqa: E731
             g_b4, g_w4 = gb.grad_bias(gx), gw(gx, h3)
-            g_pre3 = _ew(_lib.EW_MUL, lin(gx, tr(w4)), d3)
+            g_pre3 = _ew(_lib.EW_MUL, lin(gx, w4t), d3)
             del h3, d3
             g_b3 = gb.grad_bias(g_pre3)
             g_w3 = [gw(g_pre3, x_dst), gw(g_pre3, agg)]
-            g_agg = lin(g_pre3, tr(wa))
-            g_xd = _ew(_lib.EW_ADD, lin(g_pre3, tr(wx_)), gx)
+            g_agg = lin(g_pre3, wat)
+            g_xd = _ew(_lib.EW_ADD, lin(g_pre3, wxt), gx)
             del g_pre3, agg
             # ---- messages and edge MLP ----------------------------------------------------------------------------
             if _lib.lib().gwen_mlp2_bwd_supported(f):
@@ -413,12 +420,11 @@ class _InteractionNetFunction(torch.autograd.Function):
                 # (a block without an edge output -- the encoder / decoder blocks -- has ge = 0: the same launch on a
                 #  zero array still replaces four launches and nine passes, and ge's own gradient terms drop out)
                 g_agg_s = g_agg * g.inv_degree().view(-1, 1) if mean else g_agg
-                g_pre1, g_e = _edge_backward(ge if has_ge else torch.zeros_like(e), tr(w2), d1,
-                                             lin(g_agg_s, tr(w2)), g.dst, tr(we))
+                g_pre1, g_e = _edge_backward(ge if has_ge else torch.zeros_like(e), w2t, d1,
+                                             lin(g_agg_s, w2t), g.dst, wet)
                 del d1
                 hagg = _segsum(g.segments("dst"), h1, n_dst)
-                deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float32).view(-1, 1)
-                g_b2 = (g_agg_s * deg).sum(0)
+                g_b2 = gb.grad_bias(g_agg_s * g.degree())
                 g_w2 = gw(g_agg_s, hagg)
                 g_b2e, g_w2e = (gb.grad_bias(ge), gw(ge, h1)) if has_ge else (None, None)
                 del h1, hagg, g_agg, g_agg_s
@@ -427,8 +433,8 @@ class _InteractionNetFunction(torch.autograd.Function):
                 big_s = _segsum(g.segments("src"), g_pre1, n_src)
                 g_w1 = [gw(g_pre1, e), gw(big_s, x_src), gw(big_d, x_dst)]
                 del g_pre1
-                g_xs = lin(big_s, tr(ws_))
-                g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, tr(wd_)))
+                g_xs = lin(big_s, wst)
+                g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, wdt))
                 if same:
                     g_xd = _ew(_lib.EW_ADD, g_xd, g_xs)
                     g_xs = None
@@ -443,7 +449,7 @@ class _InteractionNetFunction(torch.autograd.Function):
                         pick(14, g_b4))
             g_m = _gather_add(ge, g_agg, g.dst, g.inv_degree() if mean else None)
             g_b2, g_w2 = gb.grad_bias(g_m), gw(g_m, h1)
-            g_pre1 = _ew(_lib.EW_MUL, lin(g_m, tr(w2)), d1)
+            g_pre1 = _ew(_lib.EW_MUL, lin(g_m, w2t), d1)
             del g_m, h1, d1, g_agg
             big_d = _segsum(g.segments("dst"), g_pre1, n_dst)          # per target: sum over its in-edges
             g_b1 = gb.grad_bias(big_d)                                 # = column sums of g_pre1, over N_dst rows instead of E
@@ -451,12 +457,12 @@ class _InteractionNetFunction(torch.autograd.Function):
             g_w1 = [gw(g_pre1, e), gw(big_s, x_src), gw(big_d, x_dst)]
             gb.finish()
             g_w1, g_w3 = torch.cat(g_w1, dim=1), torch.cat(g_w3, dim=1)
-            g_e = lin(g_pre1, tr(we))
+            g_e = lin(g_pre1, wet)
             if has_ge:
                 g_e = _ew(_lib.EW_ADD, g_e, ge)
             del g_pre1
-            g_xs = lin(big_s, tr(ws_))
-            g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, tr(wd_)))
+            g_xs = lin(big_s, wst)
+            g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, wdt))
             if same:           # x_src is x_dst: one tensor in two argument slots -- its gradient is reported once
                 g_xd = _ew(_lib.EW_ADD, g_xd, g_xs)
                 g_xs = None
