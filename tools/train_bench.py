@@ -1,5 +1,5 @@
 """Training step (forward + L1 loss on masked rows + backward + Adam) of GNNModel on the c2 mesh and on the
-reference's own shape: ms per step.   python tools/train_bench.py [mesh|ref] [fused] [graph]
+reference's own shape: ms per step.   python tools/train_bench.py [mesh|mesh256|ref] [fused] [graph]
 fused: torch.optim.Adam(fused=True);  graph: the WHOLE step (forward, loss, backward, Adam) captured once into a
 hipGraph (torch.cuda.CUDAGraph) and replayed -- every launcher of libgwen_hip.so is capturable (no allocation, no
 synchronisation inside), so the step leaves the host's per-launch cost behind."""
@@ -9,9 +9,9 @@ import torch, gwen_amd
 which = sys.argv[1] if len(sys.argv) > 1 else "mesh"
 dev = "cuda:0"
 torch.manual_seed(23)
-if which == "mesh":
+if which in ("mesh", "mesh256"):                   # c2's model / the same stack at c3's 256 channels
     mesh = gwen_amd.geodesic_mesh(100, reorder="hilbert")
-    n, c, h = mesh.num_nodes, 64, 64
+    n, c, h = mesh.num_nodes, (64 if which == "mesh" else 256), (64 if which == "mesh" else 256)
     ei = torch.from_numpy(mesh.edge_index).to(dev)
 else:
     n, c, h = 125, 16384, 1024
