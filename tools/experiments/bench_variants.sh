@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for n in ${1:-product}; do
   if [ "$n" = product ]; then unset GWEN_HIP_LIB; else export GWEN_HIP_LIB=$PWD/gwen_amd/variants/libgwen_hip.$n.so; fi
   echo "=== $n" | tee -a gpurun_out/bench_variants.log
-  timeout -k 10 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-edge-mlp --no-exact 2>&1 | tail -1 > gpurun_out/bv_$n.json
+  timeout -k 10 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-edge-mlp --no-exact --allow-variant --no-live-traffic 2>&1 | tail -1 > gpurun_out/bv_$n.json
   python - "$n" <<'PY' | tee -a gpurun_out/bench_variants.log
 import json, sys
 d = json.load(open(f"gpurun_out/bv_{sys.argv[1]}.json"))
