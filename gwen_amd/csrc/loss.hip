@@ -10,11 +10,27 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// rows picked by the mask: one block, 16 mask bytes per load (a byte per load and 98 dependent trips cost 22.7 us on
+// 100 002 nodes -- 4 % of the c2 training step's kernels), unaligned heads / tails byte by byte; an integer count, exact
+// in any order
+__device__ inline int nonzero_bytes(uint32_t w) {
+  const uint32_t m = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+  return __builtin_popcount(m);
+}
 __global__ __launch_bounds__(1024) void k_mask_count(const uint8_t *__restrict__ mask, int64_t N,
                                                      float *__restrict__ ws) {
   __shared__ int32_t part[1024];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t head = N < 16 ? N : (int64_t)((16 - (reinterpret_cast<uintptr_t>(mask) & 15)) & 15);   // bytes before alignment
+  const int64_t nvec = (N - head) / 16;
+  const u32x4 *v = reinterpret_cast<const u32x4 *>(mask + head);
   int32_t c = 0;
-  for (int64_t i = threadIdx.x; i < N; i += 1024) c += mask[i] != 0;
+  for (int64_t i = threadIdx.x; i < nvec; i += 1024) {
+    const u32x4 w = v[i];
+    c += nonzero_bytes(w[0]) + nonzero_bytes(w[1]) + nonzero_bytes(w[2]) + nonzero_bytes(w[3]);
+  }
+  for (int64_t i = threadIdx.x; i < head; i += 1024) c += mask[i] != 0;
+  for (int64_t i = head + nvec * 16 + threadIdx.x; i < N; i += 1024) c += mask[i] != 0;
   part[threadIdx.x] = c;
   __syncthreads();
   for (int s = 512; s > 0; s >>= 1) {

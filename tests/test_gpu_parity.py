@@ -770,6 +770,26 @@ def test_masked_l1_fused_vs_reference_formula(ga, members, n, c):
     assert torch.allclose(od.grad.cpu().double(), 0.5 * o64.grad, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("offset,n", [(1, 1000), (7, 33), (15, 16), (3, 5), (0, 17), (9, 100002)])
+def test_masked_l1_mask_at_any_byte_offset(ga, offset, n):
+    """The picked-row count reads the mask 16 bytes at a time: masks that start at any byte offset of their storage (a view)
+    and lengths with heads / tails shorter than a vector give the same loss as an aligned copy, and the reference formula."""
+    g = torch.Generator().manual_seed(SEED + offset + n)
+    o, t = torch.randn(n, 8, generator=g), torch.randn(n, 8, generator=g)
+    store = torch.zeros(n + 32, dtype=torch.bool, device=DEV)
+    mask = torch.rand(n, generator=g) < 0.4
+    mask[n - 1] = True
+    store[offset:offset + n] = mask.to(DEV)
+    store[:offset] = True                                              # bytes outside the view must not be counted
+    store[offset + n:] = True
+    view = store[offset:offset + n]
+    assert view.data_ptr() % 16 == offset % 16
+    got = ga.loss_func(o.to(DEV), t.to(DEV), view)
+    assert torch.equal(got, ga.loss_func(o.to(DEV), t.to(DEV), mask.to(DEV)))
+    want = torch.nn.functional.l1_loss(o.double()[mask], t.double()[mask])
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+
+
 def test_masked_l1_empty_mask_is_nan_like_torch(ga):
     o = torch.randn(64, 8, device=DEV)
     none = torch.zeros(64, dtype=torch.bool, device=DEV)
