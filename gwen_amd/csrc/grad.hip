@@ -86,6 +86,56 @@ __global__ __launch_bounds__(kThreads) void k_grad_w(const float *__restrict__ g
   }
 }
 
+// The same for gradients of ONE or TWO 32 x 32 tiles (the narrow layers of the c2 model: 32 x 16, 16 x 16, 64 x 32 ...),
+// where three or two of the block's four waves had nothing to do and a launch was 391 single waves (16.5 us each on
+// 100 002 rows, latency-bound): a tile's 16-row steps are dealt over P = 4 / tiles waves, whose accumulators are added in
+// phase order through LDS at the end (fixed order: bitwise reproducible).
+template <int P>
+__global__ __launch_bounds__(kThreads) void k_grad_w_few(const float *__restrict__ g, const float *__restrict__ x,
+                                                         float *__restrict__ dst, int64_t rows, int Fin, int Fout,
+                                                         int64_t ldg, int64_t ldx, int tiles_i, int ntiles) {
+  __shared__ float red[4 * 16 * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile = wave / P, ph = wave % P;
+  const bool live = tile < ntiles;
+  const int o0 = live ? (tile / tiles_i) * 32 : 0, i0 = live ? (tile % tiles_i) * 32 : 0;
+  const int64_t r0 = (int64_t)blockIdx.x * kChunkRows;
+  const int64_t r1 = (r0 + kChunkRows < rows) ? r0 + kChunkRows : rows;
+  const bool ao = o0 + li < Fout, ai = i0 + li < Fin;
+  const float *gp = g + (ao ? o0 + li : Fout - 1), *xp = x + (ai ? i0 + li : Fin - 1);
+  f32x16 acc = {};
+  if (live) {
+    for (int64_t r = r0 + lh + 2 * kU * ph; r < r1 + lh; r += 2 * kU * P) {     // every lane of a wave: the same trip count
+      float a[kU], b[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t rr = r + 2 * u, rc = rr < r1 ? rr : r1 - 1;
+        a[u] = gp[rc * ldg];
+        b[u] = xp[rc * ldx];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool in = r + 2 * u < r1;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((in && ao) ? a[u] : 0.0f, (in && ai) ? b[u] : 0.0f, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
+  __syncthreads();
+  if (!live || ph != 0 || !ai) return;
+  float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    float v = acc[t];
+#pragma unroll
+    for (int q = 1; q < P; ++q) v = v + red[((wave + q) * 16 + t) * 64 + lane];
+    const int o = o0 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+    if (o < Fout) d[(int64_t)o * Fin + i0 + li] = v;
+  }
+}
+
 // grad_W for WIDE layers on the split contractions (round 4).  At 256 channels the fp32-input MFMA above is the whole
 // cost of a training step's weight gradients (InteractionNet forecaster, 600 000 edge rows: 54 launches, 27 of the step's
 // 59 ms): 1/16 of the bf16 matrix rate, every operand value read by 8 waves.  Here one wave owns a 64 x 64 tile of
@@ -360,7 +410,9 @@ int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int6
   const int64_t ntiles = (int64_t)tiles_i * tiles_o;
   if (ntiles > 4 * 65535LL || nc > 0x7fffffffLL) return GWEN_ERANGE;
   dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
-  k_grad_w<<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, (int)ntiles);
+  if (ntiles == 1) k_grad_w_few<4><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, (int)ntiles);
+  else if (ntiles == 2) k_grad_w_few<2><<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, (int)ntiles);
+  else k_grad_w<<<grid, kThreads, 0, st>>>(g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, tiles_i, (int)ntiles);
   GWEN_LAUNCH_CHECK();
   return GWEN_OK;
 }

@@ -640,12 +640,14 @@ def test_linear_autograd_vs_fp64(ga, contract, tol, rows, fin, fout, relu, use_b
 
 @pytest.mark.parametrize("rows,fout,fin", [(5000, 128, 128), (70001, 256, 256), (3000, 256, 64), (2047, 64, 256),
                                            (2049, 128, 256), (1, 256, 256), (4096, 192, 128), (300, 64, 64), (777, 20, 48),
-                                           (200000, 64, 64), (150001, 128, 64)])
+                                           (200000, 64, 64), (150001, 128, 64), (100002, 32, 16), (5000, 16, 32),
+                                           (1, 16, 16), (513, 64, 32), (40000, 48, 64)])
 def test_grad_weight_every_contraction_vs_fp64(ga, rows, fout, fin):
     """ops.grad_weight = g^T x on every contraction against fp64: widths the split kernels take (multiples of 64 from
     64 x 64: 64 x 64 tiles, LDS-staged, 256 .. 2 048 rows per block by row count -- one row, one row short of / past a
     chunk, a 192-wide side, row counts whose partial sums fill the workspace to its last slot) and widths that stay on
-    the fp32-input MFMA whatever is asked; rows of very different magnitude; two runs
+    the fp32-input MFMA whatever is asked (one / two 32 x 32 tiles: their row steps dealt over the block's waves; more: a wave a
+    tile); rows of very different magnitude; two runs
     bitwise equal (fixed summation order)."""
     from gwen_amd import ops
     gen = torch.Generator().manual_seed(SEED + rows)
