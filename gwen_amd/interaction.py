@@ -273,7 +273,8 @@ class InteractionNet(nn.Module):
                           graph=graph, mean=self.aggr == "mean", want_out=update_edges)
         x_new, _ = mlp2(agg, wa, self.node_mlp[2].weight, self.node_mlp[2].bias, g1=q,
                         res=x_dst, act=self.activation)
-        return (x_new, e_new, agg) if return_agg else (x_new, e_new)
+        # (training keeps the aggregate and the node projections: node-sized arrays this pass makes anyway)
+        return (x_new, e_new, agg, p, None if x_src is x_dst else ps) if return_agg else (x_new, e_new)
 
 
 # ---- pieces of the backward (csrc/interact_bwd.hip + K2 / K3 / the gradient reductions) -------------------------
@@ -343,8 +344,8 @@ def _segsum(seg: Tuple[Tensor, Tensor, Tensor], h: Tensor, rows: int) -> Tensor:
 
 class _InteractionNetFunction(torch.autograd.Function):
     """Training through an InteractionNet block, forward AND backward on libgwen_hip.so.  The forward runs on K6 and
-    keeps ONE intermediate, the aggregated messages (a node-sized array the edge kernel produces anyway: keeping it
-    saves the backward an edge-sized projection and a segmented sum); the backward recomputes the two hidden layers
+    keeps the node-sized intermediates it makes anyway -- the aggregated messages (saves the backward an edge-sized
+    projection and a segmented sum) and the node projections [Ps | Pd | Q]; the backward recomputes the two hidden layers
     (K3 + ``gwen_act_pair_f32``, which also yields the activation's derivative) and then walks the block in reverse:
         node MLP:  g_pre3 = (gx W4) * act'(pre3);   g_agg = g_pre3 Wa;   g_x += gx + g_pre3 Wx
         messages:  g_m[e] = ge[e] + g_agg[dst(e)] (/ degree for the mean)          (``gwen_gather_add_f32``)
@@ -359,9 +360,10 @@ class _InteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, graph, update_edges, same, x_src, x_dst, e, *params):
         with torch.no_grad():
-            x_new, e_new, agg = net._forward_k6(x_dst if same else x_src, x_dst, e, graph, update_edges, return_agg=True)
+            x_new, e_new, agg, proj, ps = net._forward_k6(x_dst if same else x_src, x_dst, e, graph, update_edges,
+                                                          return_agg=True)
         ctx.net, ctx.graph, ctx.update_edges, ctx.same = net, graph, update_edges, same
-        ctx.save_for_backward(x_src, x_dst, e, agg, *params)
+        ctx.save_for_backward(x_src, x_dst, e, agg, *params, proj, proj.new_empty(0) if ps is None else ps)
         if e_new is None:
             e_new = e.new_empty(0)
             ctx.mark_non_differentiable(e_new)
@@ -369,7 +371,7 @@ class _InteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gx, ge):
-        x_src, x_dst, e, agg, w1, b1, w2, b2, w3, b3, w4, b4 = ctx.saved_tensors
+        x_src, x_dst, e, agg, w1, b1, w2, b2, w3, b3, w4, b4, pall, ps = ctx.saved_tensors
         net, g, same = ctx.net, ctx.graph, ctx.same
         f, act, mean = net.channels, net.activation, net.aggr == "mean"
         n_src, n_dst = g.num_src, g.num_dst
@@ -383,16 +385,14 @@ class _InteractionNetFunction(torch.autograd.Function):
             # contiguous): w1 = [We | Ws | Wd], w3 = [Wx | Wa]  (thirteen slice / transpose copies a block before)
             w1t, w3t, w2t, w4t = (w.t().contiguous() for w in (w1, w3, w2, w4))
             wet, wst, wdt, wxt, wat = w1t[:f], w1t[f:2 * f], w1t[2 * f:], w3t[:f], w3t[f:]
-            # ---- the two hidden layers again (the forward kept nothing) -----------------------------------------
-            # the node-side projections as the forward makes them: ONE stacked launch [Ps | Pd | Q] when x_src is x_dst
-            # (two when not); the kernels below read the column blocks through a row stride
-            we, wa, wn, bn = net._weight_blocks()
+            # ---- the two hidden layers again ------------------------------------------------------------------------
+            # the node-side projections [Ps | Pd | Q] (stacked when x_src is x_dst) are the forward's own, kept (node-sized:
+            # 3 F floats a node -- recomputing them was three launches of the dense kernel a block, 3 % of the step); the
+            # kernels below read the column blocks through a row stride
+            we, wa, _, _ = net._weight_blocks()
             if same:
-                pall = lin(x_dst, wn, bn)
                 ps, pd, q = pall[:, :f], pall[:, f:2 * f], pall[:, 2 * f:]
             else:
-                ps = lin(x_src, wn[:f])
-                pall = lin(x_dst, wn[f:], bn[f:])
                 pd, q = pall[:, :f], pall[:, f:]
             h1, d1 = _act_pair(lin(e, we), act, ps, g.src, pd, g.dst)
             del ps, pd                                   # (agg = sum / mean of the messages: kept by the forward)

@@ -43,7 +43,8 @@ def timed(k=10):
 
 def torch_backward(ctx, gx, ge):
     """Round 2's backward: recompute the block in torch device ops under autograd (library kernels, float atomics)."""
-    x_src, x_dst, e, _agg, *params = ctx.saved_tensors       # (_agg: the forward's aggregate, kept for the product's backward)
+    x_src, x_dst, e = ctx.saved_tensors[:3]                  # ([3]: the forward's aggregate, [12:]: its node projections --
+    params = ctx.saved_tensors[4:12]                         #  kept for the product's backward)
     net, graph, f = ctx.net, ctx.graph, ctx.net.channels
     act = {"none": lambda v: v, "relu": torch.relu, "silu": torch.nn.functional.silu}[net.activation]
     need = ctx.needs_input_grad[4:]
