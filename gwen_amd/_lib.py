@@ -147,6 +147,8 @@ SIGNATURES = {
     "gwen_gcn_grad_weight_partial_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "gwen_gcn_grad_weight_chunks": (_i64, [_i64, _i64, _i64, _int]),
     "gwen_gcn_grad_bias_partial_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "gwen_gcn_grad_weight_bias_supported": (_int, [_i64, _i64, _int]),
+    "gwen_gcn_grad_weight_bias_partial_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "gwen_reduce_chunks_batched": (_int, [_vp, C.c_int32, _vp]),
     "gwen_transpose_batched": (_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     "gwen_gcn_small_pad": (_int, [_i64]),

@@ -219,10 +219,13 @@ __global__ __launch_bounds__(kThreads) void k_grad_w_split(const float *__restri
 // column from the row-major tile (consecutive lanes = consecutive dwords: conflict-free).  One barrier per step; the
 // DMAs are inline asm (hipcc neither counts nor drains them) and the only visible vector-memory instructions are the
 // tile's stores after the loop.
-template <int NS, int BO, int BI>
+// BIAS: the chunk's column sums of g as well (grad_b of the same layer: the g tile is in LDS anyway) -- the waves that
+// own the block's first 64 x-columns, in the blocks of the first x-column tile, add their g values per column as they
+// cut them; bdst [chunks, Fout].
+template <int NS, int BO, int BI, bool BIAS = false>
 __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
     const float *__restrict__ g, const float *__restrict__ x, float *__restrict__ dst, int64_t rows, int Fin, int Fout,
-    int64_t ldg, int64_t ldx, int tiles_i, int chunk_rows) {
+    int64_t ldg, int64_t ldx, int tiles_i, int chunk_rows, float *__restrict__ bdst = nullptr) {
   constexpr int NWB = (BO / 64) * (BI / 64);                 // waves per block
   constexpr int kStepBytes = 16 * (BO + BI) * 4;             // one step's tiles: g [16][BO] | x [16][BI]
   constexpr int PG = BO / 16, NPC = (BO + BI) / 16, PPW = NPC / NWB;     // 1-KiB pieces: of g, in all, per wave
@@ -252,6 +255,8 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
     });
   };
   f32x16 acc[2][2] = {};
+  float bsum[2] = {0.0f, 0.0f};
+  const bool bias_wave = BIAS && wi == 0 && (int)blockIdx.y % tiles_i == 0;      // wave-uniform
   issue(0, 0);
   // one 16-row step; TAIL = the chunk's last step, the only one that can hold rows past the chunk (zeroed as they are
   // read: the 16 compare + select pairs are not paid in the other steps)
@@ -271,6 +276,9 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
         av[t] = (!TAIL || st * 16 + 8 * lh + t < nrows) ? a : 0.0f;
         bv[t] = lx[(8 * lh + t) * BI + 64 * wi + 32 * s + li];
       }
+      if constexpr (BIAS) {
+        if (bias_wave) bsum[s] = bsum[s] + (((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7])));
+      }
       gwen::split_images<8, NS>(av, ai[s]);
       gwen::split_images<8, NS>(bv, bi[s]);
     }
@@ -281,6 +289,15 @@ __global__ __launch_bounds__((BO / 64) * (BI / 64) * 64) void k_grad_w_lds(
   };
   for (int st = 0; st + 1 < nsteps; ++st) step(st, std::false_type{});
   step(nsteps - 1, std::true_type{});
+  if constexpr (BIAS) {
+    if (bias_wave) {                                  // rows 8 lh + t of every step: the two halves of a column meet here
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float v = bsum[s] + __shfl_xor(bsum[s], 32);
+        if (lh == 0) bdst[(int64_t)blockIdx.x * Fout + o0 + 64 * wo + 32 * s + li] = v;
+      }
+    }
+  }
   float *d = dst + (int64_t)blockIdx.x * Fout * Fin;
 #pragma unroll
   for (int so = 0; so < 2; ++so)
@@ -372,12 +389,13 @@ inline int64_t nchunks_w(int64_t rows, int64_t Fin, int64_t Fout, int contract) 
 
 // stage 1 of grad_W into `dst` ([slots, Fout * Fin]; slots = nchunks_w)
 int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int64_t Fin, int64_t Fout, int64_t ldg,
-                  int64_t ldx, int contract, hipStream_t st) {
+                  int64_t ldx, int contract, hipStream_t st, float *bdst = nullptr) {
   if (wide_grad(Fin, Fout, contract)) {
     const int64_t nc = nchunks_w(rows, Fin, Fout, contract);
     const int cr = split_chunk_rows(rows, Fin, Fout);
     if (nc > 0x7fffffffLL || ldg * 4 * cr >= (int64_t(1) << 31) || ldx * 4 * cr >= (int64_t(1) << 31)) return GWEN_ERANGE;
     if (!gwen_aligned(g, 16) || !gwen_aligned(x, 16) || ldg % 4 || ldx % 4) {     // (the DMA moves 16-byte pieces)
+      if (bdst) return GWEN_EINVAL;                 // the fused column sums exist on the LDS-staged kernel only
       const int tiles_i = (int)(Fin / 64), ntiles = (int)(Fin / 64 * (Fout / 64));
       if ((ntiles + 3) / 4 > 65535) return GWEN_ERANGE;
       dim3 grid((unsigned)nc, (unsigned)((ntiles + 3) / 4));
@@ -393,6 +411,10 @@ int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int6
     const int ti = (int)(Fin / BI_);                                                                               \
     const int64_t nt = (int64_t)ti * (Fout / BO_);                                                                 \
     if (nt > 65535) return GWEN_ERANGE;                                                                            \
+    if (bdst)                                                                                                      \
+      k_grad_w_lds<NS_, BO_, BI_, true><<<dim3((unsigned)nc, (unsigned)nt), (BO_ / 64) * (BI_ / 64) * 64, 0, st>>>(\
+          g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, ti, cr, bdst);                                           \
+    else                                                                                                           \
     k_grad_w_lds<NS_, BO_, BI_><<<dim3((unsigned)nc, (unsigned)nt), (BO_ / 64) * (BI_ / 64) * 64, 0, st>>>(        \
         g, x, dst, rows, (int)Fin, (int)Fout, ldg, ldx, ti, cr);                                                   \
   } while (0)
@@ -405,6 +427,7 @@ int launch_grad_w(const float *g, const float *x, float *dst, int64_t rows, int6
     GWEN_LAUNCH_CHECK();
     return GWEN_OK;
   }
+  if (bdst) return GWEN_EINVAL;
   const int64_t nc = nchunks_for(rows);
   const int tiles_i = (int)((Fin + 31) / 32), tiles_o = (int)((Fout + 31) / 32);
   const int64_t ntiles = (int64_t)tiles_i * tiles_o;
@@ -539,6 +562,22 @@ extern "C" int gwen_gcn_grad_weight_partial_f32(const float *g, const float *x, 
     return GWEN_EINVAL;
   if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
   return launch_grad_w(g, x, partial, rows, Fin, Fout, ldg, ldx, gwen_dense_contract(contract), gwen_stream(stream_));
+}
+
+extern "C" int gwen_gcn_grad_weight_bias_supported(int64_t Fin, int64_t Fout, int contract) {
+  return contract >= 0 && contract <= GWEN_CONTRACT_F16X3 && wide_grad(Fin, Fout, gwen_dense_contract(contract)) ? 1 : 0;
+}
+
+extern "C" int gwen_gcn_grad_weight_bias_partial_f32(const float *g, const float *x, float *partial_w, float *partial_b,
+                                                     int64_t rows, int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx,
+                                                     int contract, gwen_stream_t stream_) {
+  if (rows <= 0 || Fin <= 0 || Fout <= 0 || ldg < Fout || ldx < Fin || !g || !x || !partial_w || !partial_b ||
+      contract < 0 || contract > GWEN_CONTRACT_F16X3)
+    return GWEN_EINVAL;
+  if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
+  if (!gwen_gcn_grad_weight_bias_supported(Fin, Fout, contract)) return GWEN_EINVAL;
+  return launch_grad_w(g, x, partial_w, rows, Fin, Fout, ldg, ldx, gwen_dense_contract(contract), gwen_stream(stream_),
+                       partial_b);
 }
 
 extern "C" int gwen_gcn_grad_bias_partial_f32(const float *g, float *partial, int64_t rows, int64_t F,

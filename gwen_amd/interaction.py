@@ -403,11 +403,12 @@ class _InteractionNetFunction(torch.autograd.Function):
             #  all of them in ONE launch at the end -- ops.GradBatch)
             gb = ops.GradBatch()
             gw = lambda a, b_: gb.grad_weight(a, b_, _BWD_CONTRACT)                          # noqa: E731
-            g_b4, g_w4 = gb.grad_bias(gx), gw(gx, h3)
+            gwb = lambda a, b_: gb.grad_weight_bias(a, b_, _BWD_CONTRACT)                    # noqa: E731
+            g_w4, g_b4 = gwb(gx, h3)                                   # (weight gradient + column sums of the same rows)
             g_pre3 = _ew(_lib.EW_MUL, lin(gx, w4t), d3)
             del h3, d3
-            g_b3 = gb.grad_bias(g_pre3)
-            g_w3 = [gw(g_pre3, x_dst), gw(g_pre3, agg)]
+            g_w3a, g_b3 = gwb(g_pre3, x_dst)
+            g_w3 = [g_w3a, gw(g_pre3, agg)]
             g_agg = lin(g_pre3, wat)
             g_xd = _ew(_lib.EW_ADD, lin(g_pre3, wxt), gx)
             del g_pre3, agg
@@ -426,12 +427,12 @@ class _InteractionNetFunction(torch.autograd.Function):
                 hagg = _segsum(g.segments("dst"), h1, n_dst)
                 g_b2 = gb.grad_bias(g_agg_s * g.degree())
                 g_w2 = gw(g_agg_s, hagg)
-                g_b2e, g_w2e = (gb.grad_bias(ge), gw(ge, h1)) if has_ge else (None, None)
+                g_w2e, g_b2e = gwb(ge, h1) if has_ge else (None, None)
                 del h1, hagg, g_agg, g_agg_s
                 big_d = _segsum(g.segments("dst"), g_pre1, n_dst)
-                g_b1 = gb.grad_bias(big_d)
                 big_s = _segsum(g.segments("src"), g_pre1, n_src)
-                g_w1 = [gw(g_pre1, e), gw(big_s, x_src), gw(big_d, x_dst)]
+                g_w1d, g_b1 = gwb(big_d, x_dst)
+                g_w1 = [gw(g_pre1, e), gw(big_s, x_src), g_w1d]
                 del g_pre1
                 g_xs = lin(big_s, wst)
                 g_xd = _ew(_lib.EW_ADD, g_xd, lin(big_d, wdt))

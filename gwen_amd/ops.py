@@ -367,6 +367,32 @@ class GradBatch:
             self._add(dst, out, fout * fin, nch)
         return out
 
+    def grad_weight_bias(self, g: Tensor, x: Tensor, contract: Optional[str] = None):
+        """(g^T x, column sums of g): ONE stage-1 launch where the weight gradient runs on the LDS-staged split kernel (the
+        g tile is in LDS anyway), the two separate launches elsewhere."""
+        g = g.contiguous(); x = x.contiguous()
+        fout, fin = g.size(-1), x.size(-1)
+        rows = math.prod(g.shape[:-1])
+        code = _contract_code(contract)
+        L = _lib.lib()
+        if rows == 0 or not L.gwen_gcn_grad_weight_bias_supported(fin, fout, code) or g.data_ptr() % 16 \
+                or x.data_ptr() % 16:
+            return self.grad_weight(g, x, contract), self.grad_bias(g)
+        dev = self._dev = g.device
+        gw = torch.empty(fout, fin, dtype=torch.float32, device=dev)
+        gb = torch.empty(fout, dtype=torch.float32, device=dev)
+        nch = int(L.gwen_gcn_grad_weight_chunks(rows, fin, fout, code))
+        pw = gw if nch == 1 else torch.empty(nch * fout * fin, dtype=torch.float32, device=dev)
+        pb = gb if nch == 1 else torch.empty(nch * fout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.gwen_gcn_grad_weight_bias_partial_f32(_ptr(g), _ptr(x), _ptr(pw), _ptr(pb), rows, fin, fout, fout, fin,
+                                                         code, _stream(dev))
+        _lib.check(rc, "gwen_gcn_grad_weight_bias_partial_f32")
+        if nch > 1:
+            self._add(pw, gw, fout * fin, nch)
+            self._add(pb, gb, fout, nch)
+        return gw, gb
+
     def grad_bias(self, g: Tensor) -> Tensor:
         g = g.contiguous()
         f = g.size(-1)

@@ -410,6 +410,14 @@ int gwen_gcn_grad_weight_partial_f32(const float *g, const float *x, float *part
                                      gwen_stream_t stream);
 int gwen_gcn_grad_bias_partial_f32(const float *g, float *partial, int64_t rows, int64_t F, int64_t ldg,
                                    gwen_stream_t stream);
+/* Stage 1 of grad_W = g^T x AND of grad_b = column sums of g in ONE launch (the g tile is staged anyway), where the
+ * weight gradient runs on the LDS-staged split kernel: gwen_gcn_grad_weight_bias_supported(Fin, Fout, contract) -- widths
+ * that are multiples of 64 on a split contraction; g, x 16-byte aligned with ldg, ldx multiples of 4 (GWEN_EINVAL
+ * otherwise: use the two separate launches).  partial_w as above; partial_b [gwen_gcn_grad_weight_chunks(...), Fout]. */
+int gwen_gcn_grad_weight_bias_supported(int64_t Fin, int64_t Fout, int contract);
+int gwen_gcn_grad_weight_bias_partial_f32(const float *g, const float *x, float *partial_w, float *partial_b,
+                                          int64_t rows, int64_t Fin, int64_t Fout, int64_t ldg, int64_t ldx,
+                                          int contract, gwen_stream_t stream);
 int gwen_reduce_chunks_batched(const gwen_reduce_task *tasks, int32_t n_tasks, gwen_stream_t stream);
 int gwen_transpose_batched(const float *const *w, float *const *wt, const int32_t *rows,
                            const int32_t *cols, int32_t n, gwen_stream_t stream);

@@ -694,6 +694,30 @@ def test_grad_batch_many_reductions_one_finish(ga):
             assert rel_err(gotb, g.double().sum(0)) <= 2e-6 if g.size(0) else not bool(gotb.any())
 
 
+@pytest.mark.parametrize("rows,fout,fin", [(70001, 256, 256), (5000, 128, 128), (600, 64, 64), (2049, 128, 256),
+                                           (100002, 64, 128), (3000, 192, 64), (777, 20, 48), (1, 64, 64)])
+def test_grad_weight_bias_one_launch(ga, rows, fout, fin):
+    """GradBatch.grad_weight_bias: grad_W AND the column sums of the same g from one stage-1 launch where the LDS-staged
+    kernel takes the weight gradient (every block shape: 128 x 128, 128 x 64, 64 x 128, 64 x 64; one chunk and many),
+    the two separate launches elsewhere (20 x 48) -- both against fp64, the weight gradient bitwise the plain one."""
+    from gwen_amd import ops
+    gen = torch.Generator().manual_seed(SEED + rows + fout)
+    g = (torch.randn(rows, fout, generator=gen) * torch.exp2(torch.randint(-6, 7, (rows, 1), generator=gen).float())).to(DEV)
+    x = torch.randn(rows, fin, generator=gen).to(DEV)
+    for contract in ("3xbf16", "bf16x6"):
+        runs = []
+        for _ in range(2):
+            gb = ops.GradBatch()
+            w, b = gb.grad_weight_bias(g, x, contract)
+            gb.finish()
+            runs.append((w, b))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        w, b = runs[0]
+        assert torch.equal(w, ops.grad_weight(g, x, contract)) or rel_err(w, ops.grad_weight(g, x, contract)) <= 1e-6
+        assert rel_err(w, g.double().t() @ x.double()) <= (4e-6 if contract == "bf16x6" else 3e-5)
+        assert rel_err(b, g.double().sum(0)) <= 2e-6, rel_err(b, g.double().sum(0))
+
+
 def test_stack_backward_without_input_grad_and_determinism(ga):
     m = ga.geodesic_mesh(9, reorder="hilbert")
     ei = torch.from_numpy(m.edge_index).to(DEV)
