@@ -166,6 +166,7 @@ SIGNATURES = {
     "gwen_mlp2_workspace_bytes": (_i64, [_i64]),
     "gwen_mlp2_rows": (_int, [_i64]),
     "gwen_act_pair_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _vp]),
+    "gwen_act_pair_seg_f32": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "gwen_gather_add_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "gwen_ew_f32": (_int, [_int, _vp, _vp, _vp, _i64, _vp]),
     "gwen_mlp2_bwd_supported": (_int, [_i64]),

@@ -295,6 +295,21 @@ def _act_pair(a: Tensor, act: str, g1: Optional[Tensor] = None, idx1: Optional[T
     return a, d
 
 
+def _act_pair_seg(a: Tensor, act: str, g1: Tensor, idx1: Tensor, g2: Tensor, rowptr: Tensor, n_dst: int):
+    """gwen_act_pair_seg_f32: (act(pre), act'(pre), per-target sums of act(pre)) for edges stored by target, pre = a +
+    g1[idx1] + g2[target]; act(pre) overwrites ``a``."""
+    rows, f = a.shape
+    dev = a.device
+    d = torch.empty_like(a)
+    hsum = torch.empty(n_dst, f, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_act_pair_seg_f32(_ptr(a), _ptr(g1), _ptr(idx1), g1.stride(0), _ptr(g2), g2.stride(0),
+                                              _ptr(rowptr), _ptr(a), _ptr(d), _ptr(hsum), rows, n_dst, f, _ACT[act],
+                                              _stream(dev))
+    _lib.check(rc, "gwen_act_pair_seg_f32")
+    return a, d, hsum
+
+
 def _gather_add(a: Optional[Tensor], t: Tensor, idx: Tensor, scale: Optional[Tensor] = None) -> Tensor:
     rows, f = idx.numel(), t.size(-1)
     out = torch.empty(rows, f, dtype=torch.float32, device=t.device)
@@ -394,7 +409,11 @@ class _InteractionNetFunction(torch.autograd.Function):
                 ps, pd, q = pall[:, :f], pall[:, f:2 * f], pall[:, 2 * f:]
             else:
                 pd, q = pall[:, :f], pall[:, f:]
-            h1, d1 = _act_pair(lin(e, we), act, ps, g.src, pd, g.dst)
+            fused_edge = bool(_lib.lib().gwen_mlp2_bwd_supported(f))
+            if fused_edge:       # (edges are stored by target: the hidden layer's per-target sums come out of the same pass)
+                h1, d1, hagg = _act_pair_seg(lin(e, we), act, ps, g.src, pd, g.rowptr, n_dst)
+            else:
+                h1, d1 = _act_pair(lin(e, we), act, ps, g.src, pd, g.dst)
             del ps, pd                                   # (agg = sum / mean of the messages: kept by the forward)
             h3, d3 = _act_pair(lin(agg, wa), act, q)
             del pall, q
@@ -413,7 +432,7 @@ class _InteractionNetFunction(torch.autograd.Function):
             g_xd = _ew(_lib.EW_ADD, lin(g_pre3, wxt), gx)
             del g_pre3, agg
             # ---- messages and edge MLP ----------------------------------------------------------------------------
-            if _lib.lib().gwen_mlp2_bwd_supported(f):
+            if fused_edge:
                 # ONE launch of K6's kernel for the edge-level half (round 4): by linearity g_m W2 = ge W2 + T[dst] with
                 # T = (g_agg / degree) W2 per node, so the message gradient g_m = ge + g_agg[dst] is never formed --
                 # its two uses split the same way: g_m^T h1 = ge^T h1 + g_agg_s^T (sum of h1 over a target's edges),
@@ -424,7 +443,6 @@ class _InteractionNetFunction(torch.autograd.Function):
                 g_pre1, g_e = _edge_backward(ge if has_ge else torch.zeros_like(e), w2t, d1,
                                              lin(g_agg_s, w2t), g.dst, wet)
                 del d1
-                hagg = _segsum(g.segments("dst"), h1, n_dst)
                 g_b2 = gb.grad_bias(g_agg_s * g.degree())
                 g_w2 = gw(g_agg_s, hagg)
                 g_w2e, g_b2e = gwb(ge, h1) if has_ge else (None, None)

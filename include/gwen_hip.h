@@ -508,6 +508,10 @@ int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_
  *   gwen_act_pair_f32:   pre[r] = a[r] + g1[idx1 ? idx1[r] : r] + g2[idx2 ? idx2[r] : r]  (tables optional, row
  *                        strides ld1 / ld2 >= F);  h[r] = act(pre[r]);  dact[r] = act'(pre[r])  (dact may be NULL;
  *                        h may alias a).  a, h, dact: [rows, F] contiguous, F % 4 == 0.
+ *   gwen_act_pair_seg_f32: the same for edges STORED BY TARGET (rows rowptr[d] .. rowptr[d + 1] belong to target d, g2 is
+ *                        the target's own row: g2[d]) with the per-target sums of h in stored order as well,
+ *                        hsum[d] = sum_r h[r]  [n_dst, F] -- gwen_act_pair_f32 followed by K2 over the edge-position
+ *                        CSR, bit for bit, without the second pass over [rows, F].
  *   gwen_gather_add_f32: out[r] = (a ? a[r] : 0) + t[idx[r]] * (scale ? scale[idx[r]] : 1)   t: [*, F] contiguous.
  *   gwen_ew_f32:         out = a * b (GWEN_EW_MUL) or a + b (GWEN_EW_ADD), n % 4 == 0; out may alias a or b.
  *   gwen_mlp2_bwd_f32 (round 4): the edge-level half of the backward as ONE launch of K6's row-stationary kernel, at
@@ -524,6 +528,9 @@ int gwen_mlp2_f32(const float *A, const float *W1, const float *G1, const int32_
 int gwen_act_pair_f32(const float *a, const float *g1, const int32_t *idx1, int64_t ld1, const float *g2,
                       const int32_t *idx2, int64_t ld2, float *h, float *dact, int64_t rows, int64_t F, int act,
                       gwen_stream_t stream);
+int gwen_act_pair_seg_f32(const float *a, const float *g1, const int32_t *idx1, int64_t ld1, const float *g2,
+                          int64_t ld2, const int32_t *rowptr, float *h, float *dact, float *hsum, int64_t rows,
+                          int64_t n_dst, int64_t F, int act, gwen_stream_t stream);
 int gwen_gather_add_f32(const float *a, const float *t, const int32_t *idx, const float *scale, float *out,
                         int64_t rows, int64_t F, gwen_stream_t stream);
 int gwen_ew_f32(int op, const float *a, const float *b, float *out, int64_t n, gwen_stream_t stream);

@@ -310,6 +310,33 @@ def test_interaction_block_on_random_bipartite_graphs(ga, seed):
     assert rel_err(graph.unsort_edges(got_e), want_e) <= REL_TOL
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_act_pair_seg_is_act_pair_then_segment_sum_bitwise(ga, seed):
+    """gwen_act_pair_seg_f32 (activation + derivative + the per-target sums of the activated rows in ONE pass over edges
+    stored by target) == gwen_act_pair_f32 followed by K2 over the edge-position CSR, bit for bit: skewed target degrees
+    (empty targets, targets with hundreds of edges), every activation, the target table read through a row stride."""
+    from gwen_amd import interaction as I
+    rng = np.random.default_rng(50 + seed)
+    F = [32, 64, 128, 256, 8, 64][seed]
+    act = ["silu", "relu", "none"][seed % 3]
+    ns, nd, e = int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(1, 4000))
+    p = rng.random(nd) ** 4 + 1e-9
+    dst = rng.choice(nd, size=e, p=p / p.sum())
+    src = rng.integers(0, ns, size=e)
+    graph = I.interaction_graph(torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV), ns, nd)
+    gen = torch.Generator().manual_seed(seed)
+    a = torch.randn(e, F, generator=gen).to(DEV)
+    ps = torch.randn(ns, F, generator=gen).to(DEV)
+    pall = torch.randn(nd, 3 * F, generator=gen).to(DEV)
+    pd = pall[:, F:2 * F]                                                       # a strided view, as in the backward
+    h0, d0 = I._act_pair(a.clone(), act, ps, graph.src, pd, graph.dst)
+    s0 = I._segsum(graph.segments("dst"), h0, nd)
+    h1, d1, s1 = I._act_pair_seg(a.clone(), act, ps, graph.src, pd, graph.rowptr, nd)
+    assert torch.equal(h0, h1) and torch.equal(d0, d1) and torch.equal(s0, s1)
+    ref = torch.zeros(nd, F, dtype=torch.float64, device=DEV).index_add_(0, graph.dst.long(), h0.double())
+    assert rel_err(s1, ref) <= 1e-6
+
+
 @pytest.mark.parametrize("F,act,aggr,bip", [(32, "silu", "sum", False), (64, "relu", "mean", True),
                                            (128, "silu", "sum", True), (64, "none", "sum", False),
                                            (64, "silu", "sum", True), (256, "silu", "sum", False),
