@@ -130,6 +130,8 @@ SIGNATURES = {
                                     C.POINTER(LaunchInfo), C.c_int32, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_void_p)]),
     "gwen_gcn_layer_bwd_f32": (_int, [_vp] * 8 + [_i64] * 4 + [_int, _vp]),
+    "gwen_gcn_layer_bwd_bias_rows": (_i64, [_i64, _i64]),
+    "gwen_gcn_layer_bwd_bias_f32": (_int, [_vp] * 8 + [_i64] * 4 + [_int, _vp, _vp, _vp]),
     "gwen_gnn_backward_scratch_floats": (_i64, [_i64, _i64, C.POINTER(LayerDesc), C.c_int32]),
     "gwen_gnn_backward_f32": (_int, [C.POINTER(GraphDesc), C.POINTER(LayerDesc), C.c_int32, _vp,
                                      C.POINTER(C.c_void_p), _vp, _vp, C.POINTER(C.c_void_p),

@@ -37,8 +37,9 @@ int make_bplan(int64_t N, int64_t members, const gwen_layer_desc *layers, int32_
     wsum += round4((int64_t)L.fin * L.fout);
     P->pw_off[i] = psum;
     psum += round4(nc * L.fin * L.fout);
-    P->pb_off[i] = psum;
-    psum += round4(nc * L.fout);
+    P->pb_off[i] = psum;                           // (its column sums may come per chunk of the backward kernel above it)
+    const int64_t nb = gwen_gcn_layer_bwd_bias_rows(N, members);
+    psum += round4((nb > nc ? nb : nc) * L.fout);
   }
   P->g0 = 0;
   P->g1 = round4(rows * fmax);
@@ -96,6 +97,7 @@ extern "C" int gwen_gnn_backward_f32(const gwen_graph *graph_t, const gwen_layer
   int32_t n_tasks = 0;
 
   const float *g = grad_out;
+  bool bias_done[GWEN_MAX_REDUCE_TASKS] = {};
   int nb = 0;
   {
     const gwen_layer_desc &T = layers[n_layers - 1];
@@ -114,7 +116,7 @@ extern "C" int gwen_gnn_backward_f32(const gwen_graph *graph_t, const gwen_layer
     float *gx = l == 0 ? grad_x : gbuf[nb++ & 1];
     const float *wt = scratch + P.wt + P.wt_off[l];
     if (need_gx && gx == g) return GWEN_EINVAL;
-    if (grad_b && grad_b[l]) {
+    if (grad_b && grad_b[l] && !bias_done[l]) {
       float *pb = scratch + P.part + P.pb_off[l];
       GWEN_TRY(gwen_gcn_grad_bias_partial_f32(g, pb, rows, fo, fo, stream));
       tasks[n_tasks++] = gwen_reduce_task{pb, grad_b[l], fo, nc};
@@ -125,8 +127,15 @@ extern "C" int gwen_gnn_backward_f32(const gwen_graph *graph_t, const gwen_layer
     // f16x3) on bf16x6, explicit / fp32 orders on the fp32-input MFMA (K3 below)
     const int cc = gwen_dense_contract(gwen_contract_of(L));
     if (fused) {
-      GWEN_TRY(gwen_gcn_layer_bwd_f32(graph_t->g_rowptr, graph_t->g_col, graph_t->g_val, g, wt, mask, gh,
-                                      gx, N, fo, fi, members, cc, stream));
+      // gx is the incoming gradient of layer l - 1: the launch leaves stage 1 of that layer's grad_b as well
+      float *pbelow = (l > 0 && grad_b && grad_b[l - 1]) ? scratch + P.part + P.pb_off[l - 1] : nullptr;
+      int64_t bchunks = 0;
+      GWEN_TRY(gwen_gcn_layer_bwd_bias_f32(graph_t->g_rowptr, graph_t->g_col, graph_t->g_val, g, wt, mask, gh,
+                                           gx, N, fo, fi, members, cc, pbelow, pbelow ? &bchunks : nullptr, stream));
+      if (pbelow && bchunks > 0) {
+        tasks[n_tasks++] = gwen_reduce_task{pbelow, grad_b[l - 1], fi, bchunks};
+        bias_done[l - 1] = true;
+      }
     } else {
       GWEN_TRY(gwen_gcn_propagate_f32(graph_t->rowptr, graph_t->col, graph_t->val, g, nullptr, gh, N, fo,
                                       fo, fo, members, N * fo, N * fo, 0, stream));

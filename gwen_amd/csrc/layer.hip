@@ -72,11 +72,12 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
     const float *__restrict__ val, const float *__restrict__ x, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out, int32_t N, int64_t ldo,
     int64_t mstride_x, int64_t mstride_o, int relu, float *__restrict__ agg_out = nullptr,
-    const float *__restrict__ mask = nullptr) {
+    const float *__restrict__ mask = nullptr, float *__restrict__ bsum_out = nullptr, int32_t chunks_per_member = 0) {
   using C = Cfg<FIN, FOUT, NS, BRMIN>;
   constexpr bool SPLIT = NS > 0;
   constexpr int NI = SPLIT ? NS : 1;
   __shared__ __attribute__((aligned(16))) char lds_raw[C::lds_bytes];
+  __shared__ float bred[BWD && FIN * FOUT < 128 * 128 ? 16 * 16 : 1];    // BWD, narrow: the waves' column sums of a chunk
   float *tile = reinterpret_cast<float *>(lds_raw);                      // exact: [BR][PF] fp32
   __bf16 *timg = reinterpret_cast<__bf16 *>(lds_raw);                    // split: NS images [BR][PB]
   constexpr int kImg = C::BR * C::PB;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
   __syncthreads();
 
   // ---- phase 2: (tile) x (this wave's 16 columns of W^T), bias, ReLU, store ----------------------
+  float4_t cs = {0.f, 0.f, 0.f, 0.f};                  // BWD + bsum_out: this lane's column sums over the wave's row tiles
 #pragma unroll
   for (int tt = wave / C::NJ; tt < C::NT; tt += C::TSTEP) {
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -189,6 +191,33 @@ __global__ __launch_bounds__((FOUT > 128 ? 1024 : (FOUT > 64 ? 512 : 256))) void
       }
     }
     if (r < N) *reinterpret_cast<float4_t *>(om + (int64_t)r * ldo + j * 16 + 4 * mh) = o;
+    if constexpr (BWD && !kPersist) {
+      if (bsum_out && r < N) cs = cs + o;
+    }
+  }
+  if constexpr (BWD && !kPersist) {
+    // the chunk's column sums of the masked result (= grad_b of the layer below, whose incoming gradient this is): rows
+    // of a row tile meet through the 16 lanes that share mh, a column tile's waves through LDS in wave order; one
+    // partial row per (member, chunk), every chunk written exactly once: fixed order, no atomics.  Narrow layers only
+    // (one chunk per block): in the persistent wide kernels the extra registers cost more than the reduction launch
+    // they replace (256 -> 256: 206 -> 289 us)
+    if (bsum_out) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cs[t] = cs[t] + __shfl_xor(cs[t], m);
+      if (mi == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bred[wave * 16 + 4 * mh + t] = cs[t];
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < FOUT) {
+        const int cj = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        float v = 0.0f;
+        for (int w = cj; w < C::NWB; w += C::NJ) v = v + bred[w * 16 + cc];
+        bsum_out[((int64_t)blockIdx.y * chunks_per_member + chunk) * FOUT + threadIdx.x] = v;
+      }
+    }
   }
   if constexpr (kPersist) __syncthreads();     // the tile is free for the next chunk
   }
@@ -198,7 +227,8 @@ template <int FIN, int FOUT, int NS, int BRMIN>
 int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
                 const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
                 int64_t msx, int64_t mso, int relu, hipStream_t st, bool probe, int64_t *resident_out,
-                float *agg_out = nullptr, const float *mask = nullptr, bool bwd = false) {
+                float *agg_out = nullptr, const float *mask = nullptr, bool bwd = false, float *bsum_out = nullptr,
+                int64_t *chunks_out = nullptr) {
   using C = Cfg<FIN, FOUT, NS, BRMIN>;
   static int per_cu = 0;
   if (per_cu == 0) {
@@ -211,16 +241,20 @@ int launch_rows(const int32_t *rowptr, const int32_t *col, const float *val, con
   if (resident_out) *resident_out = resident;
   if (probe) return GWEN_OK;
   int64_t blocks = (N + C::BR - 1) / C::BR;
+  const int64_t chunks_pm = blocks;                        // chunks of BR rows per member (bsum_out: one partial row each)
+  constexpr bool kWide = FIN * FOUT >= 128 * 128;          // the persistent form: no fused column sums (see the kernel)
+  if (kWide) bsum_out = nullptr;
+  if (chunks_out) *chunks_out = kWide ? 0 : chunks_pm * members;
   if (FIN * FOUT >= 128 * 128 && blocks > resident) blocks = resident;   // wide layer: one resident set
   dim3 grid((unsigned)blocks, (unsigned)members);
   if constexpr (NS == 2 || NS == 3) {          // the backward runs on the layer's own split (bf16x3 / bf16x6)
     if (bwd) {
       if (!rowptr)
         k_layer<FIN, FOUT, NS, BRMIN, true, true><<<grid, C::NWB * 64, 0, st>>>(
-            rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask);
+            rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask, bsum_out, (int32_t)chunks_pm);
       else
         k_layer<FIN, FOUT, NS, BRMIN, false, true><<<grid, C::NWB * 64, 0, st>>>(
-            rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask);
+            rowptr, col, val, x, W, bias, out, (int32_t)N, ldo, msx, mso, relu, agg_out, mask, bsum_out, (int32_t)chunks_pm);
       GWEN_LAUNCH_CHECK();
       return GWEN_OK;
     }
@@ -239,10 +273,10 @@ template <int FIN, int FOUT, int NS>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *x,
            const float *W, const float *bias, float *out, int64_t N, int64_t ldo, int64_t members,
            int64_t msx, int64_t mso, int relu, hipStream_t st, float *agg_out = nullptr,
-           const float *mask = nullptr, bool bwd = false) {
+           const float *mask = nullptr, bool bwd = false, float *bsum_out = nullptr, int64_t *chunks_out = nullptr) {
 #define GWEN_ROWS(BRV, PROBE, RES)                                                                  \
   launch_rows<FIN, FOUT, NS, BRV>(rowptr, col, val, x, W, bias, out, N, ldo, members, msx, mso,  \
-                                     relu, st, PROBE, RES, agg_out, mask, bwd)
+                                     relu, st, PROBE, RES, agg_out, mask, bwd, bsum_out, chunks_out)
   if constexpr (FIN <= 64 && FOUT <= 64) {
     // Narrow layers run as ONE round of co-resident blocks when a block size makes that possible: with
     // 64-row blocks the c2 mesh needs 1 563 blocks against 1 024 resident ones (4 per CU at 64 -> 64),
@@ -326,10 +360,17 @@ extern "C" int gwen_gcn_layer_f32(const int32_t *rowptr, const int32_t *col, con
 // transposed CSR):  gh = A~^T g  (stored: grad_W = gh^T x is a separate reduction),  gx = gh Wt^T  masked
 // by mask > 0.  g [members, N, Fg]; Wt [Fx, Fg] = the layer's weight as stored ([out, in] = [Fg, Fx])
 // TRANSPOSED; gh [members, N, Fg]; gx, mask [members, N, Fx] (mask NULL = no ReLU below).
-extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
-                                      const float *g, const float *Wt, const float *mask, float *gh,
-                                      float *gx, int64_t N, int64_t Fg, int64_t Fx, int64_t members,
-                                      int contract, gwen_stream_t stream_) {
+// ... and, with bias_partial, the column sums of gx per (member, chunk of rows) as well: gx is the incoming gradient of
+// the layer BELOW, so these are stage 1 of that layer's grad_b -- *bias_chunks partial rows of Fx floats (at most
+// gwen_gcn_layer_bwd_bias_rows(N, members)), finished by gwen_reduce_chunks_batched.
+extern "C" int64_t gwen_gcn_layer_bwd_bias_rows(int64_t N, int64_t members) { return members * ((N + 31) / 32); }
+
+extern "C" int gwen_gcn_layer_bwd_bias_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
+                                           const float *g, const float *Wt, const float *mask, float *gh,
+                                           float *gx, int64_t N, int64_t Fg, int64_t Fx, int64_t members,
+                                           int contract, float *bias_partial, int64_t *bias_chunks,
+                                           gwen_stream_t stream_) {
+  if (bias_chunks) *bias_chunks = 0;
   if (N < 0 || members < 0 || (contract != GWEN_CONTRACT_BF16X3 && contract != GWEN_CONTRACT_BF16X6)) return GWEN_EINVAL;
   if (!gwen_gcn_layer_supported(Fg, Fx)) return GWEN_EINVAL;
   if (N == 0 || members == 0) return GWEN_OK;
@@ -339,14 +380,15 @@ extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_
       (gh && !gwen_aligned(gh, 16)) || (mask && !gwen_aligned(mask, 16)))
     return GWEN_EINVAL;
   if (N * Fg * 4 >= (int64_t(1) << 32)) return GWEN_ERANGE;
+  if ((bias_partial != nullptr) != (bias_chunks != nullptr) || (bias_partial && !gwen_aligned(bias_partial, 16))) return GWEN_EINVAL;
   hipStream_t st = gwen_stream(stream_);
 #define GWEN_L(FI, FO)                                                                           \
   if (Fg == FI && Fx == FO)                                                                      \
     return contract == GWEN_CONTRACT_BF16X6                                                      \
                ? launch<FI, FO, 3>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,  \
-                                   N * Fg, N * Fx, 0, st, gh, mask, true)                        \
+                                   N * Fg, N * Fx, 0, st, gh, mask, true, bias_partial, bias_chunks) \
                : launch<FI, FO, 2>(t_rowptr, t_col, t_val, g, Wt, nullptr, gx, N, Fx, members,  \
-                                   N * Fg, N * Fx, 0, st, gh, mask, true)
+                                   N * Fg, N * Fx, 0, st, gh, mask, true, bias_partial, bias_chunks)
   GWEN_L(16, 16); GWEN_L(16, 32); GWEN_L(16, 64); GWEN_L(16, 128);
   GWEN_L(32, 16); GWEN_L(32, 32); GWEN_L(32, 64); GWEN_L(32, 128);
   GWEN_L(64, 16); GWEN_L(64, 32); GWEN_L(64, 64); GWEN_L(64, 128);
@@ -355,4 +397,12 @@ extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_
   GWEN_L(256, 16); GWEN_L(256, 32); GWEN_L(256, 64); GWEN_L(256, 128); GWEN_L(256, 256);
 #undef GWEN_L
   return GWEN_EINVAL;
+}
+
+extern "C" int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
+                                      const float *g, const float *Wt, const float *mask, float *gh,
+                                      float *gx, int64_t N, int64_t Fg, int64_t Fx, int64_t members,
+                                      int contract, gwen_stream_t stream_) {
+  return gwen_gcn_layer_bwd_bias_f32(t_rowptr, t_col, t_val, g, Wt, mask, gh, gx, N, Fg, Fx, members, contract, nullptr,
+                                     nullptr, stream_);
 }

@@ -444,6 +444,16 @@ int gwen_transpose_batched(const float *const *w, float *const *wt, const int32_
 int gwen_gcn_layer_bwd_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val,
                            const float *g, const float *Wt, const float *mask, float *gh, float *gx,
                            int64_t N, int64_t Fg, int64_t Fx, int64_t members, int contract, gwen_stream_t stream);
+/* The same launch with stage 1 of the grad_b of the layer BELOW as well: gx is that layer's incoming gradient, and its
+ * column sums per (member, chunk of rows) cost the kernel one LDS turn -- *bias_chunks (a HOST integer, written by
+ * this call) partial rows of Fx floats go to bias_partial (room for gwen_gcn_layer_bwd_bias_rows(N, members) rows),
+ * every one written exactly once; gwen_reduce_chunks_batched finishes them in a fixed order.  bias_partial and
+ * bias_chunks both NULL: gwen_gcn_layer_bwd_f32. */
+int64_t gwen_gcn_layer_bwd_bias_rows(int64_t N, int64_t members);
+int gwen_gcn_layer_bwd_bias_f32(const int32_t *t_rowptr, const int32_t *t_col, const float *t_val, const float *g,
+                                const float *Wt, const float *mask, float *gh, float *gx, int64_t N, int64_t Fg,
+                                int64_t Fx, int64_t members, int contract, float *bias_partial,
+                                int64_t *bias_chunks, gwen_stream_t stream);
 int64_t gwen_gnn_backward_scratch_floats(int64_t N, int64_t members, const struct gwen_layer_desc *layers,
                                          int32_t n_layers);
 int gwen_gnn_backward_f32(const struct gwen_graph *graph_t, const struct gwen_layer_desc *layers,
