@@ -718,6 +718,49 @@ def test_grad_weight_bias_one_launch(ga, rows, fout, fin):
         assert rel_err(b, g.double().sum(0)) <= 2e-6, rel_err(b, g.double().sum(0))
 
 
+@pytest.mark.parametrize("fg,fx,members", [(64, 64, 1), (32, 16, 3), (16, 32, 2), (64, 32, 1), (128, 64, 1), (256, 256, 1)])
+def test_layer_bwd_leaves_the_bias_sums_of_the_layer_below(ga, fg, fx, members):
+    """gwen_gcn_layer_bwd_bias_f32 through the C ABI: the same gh / gx as gwen_gcn_layer_bwd_f32 bit for bit, and -- narrow
+    layers -- one partial row per (member, chunk of rows) whose sum is the column sum of the masked gx (stage 1 of the grad_b
+    of the layer below); the persistent wide kernels report 0 chunks and the caller keeps the separate reduction."""
+    import ctypes as C
+    from gwen_amd import _lib
+    from gwen_amd.graph import _ptr, _stream
+    m = ga.geodesic_mesh(9, reorder="hilbert")
+    n = m.num_nodes
+    g = ga.prepare_graph(torch.from_numpy(m.edge_index).to(DEV), n)
+    tr, tc, tv = g.transposed_grouped()
+    gen = torch.Generator().manual_seed(SEED + fg + fx)
+    grad = torch.randn(members, n, fg, generator=gen).to(DEV)
+    wt = (torch.randn(fx, fg, generator=gen) / fg ** 0.5).to(DEV)
+    mask = torch.randn(members, n, fx, generator=gen).to(DEV)
+    L = _lib.lib()
+    dev = torch.device(DEV)
+    outs = []
+    for with_bias in (False, True):
+        gh, gx = torch.empty_like(grad), torch.empty(members, n, fx, device=DEV)
+        rows = int(L.gwen_gcn_layer_bwd_bias_rows(n, members))
+        part = torch.full((rows, fx), float("nan"), device=DEV)
+        chunks = C.c_int64(-1)
+        args = [_ptr(tr), _ptr(tc), _ptr(tv), _ptr(grad), _ptr(wt), _ptr(mask), _ptr(gh), _ptr(gx), n, fg, fx, members,
+                _lib.CONTRACT_BF16X6]
+        if with_bias:
+            rc = L.gwen_gcn_layer_bwd_bias_f32(*args, _ptr(part), C.cast(C.pointer(chunks), C.c_void_p), _stream(dev))
+        else:
+            rc = L.gwen_gcn_layer_bwd_f32(*args, _stream(dev))
+        _lib.check(rc, "layer_bwd")
+        torch.cuda.synchronize()
+        outs.append((gh, gx, part, chunks.value))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    gh, gx, part, nch = outs[1]
+    assert bool((gx[mask <= 0] == 0).all())
+    if fg * fx >= 128 * 128:
+        assert nch == 0
+    else:
+        assert 0 < nch <= part.size(0) and bool(torch.isfinite(part[:nch]).all()) and bool(torch.isnan(part[nch:]).all())
+        assert rel_err(part[:nch].double().sum(0), gx.double().sum((0, 1))) <= 2e-6
+
+
 def test_stack_backward_without_input_grad_and_determinism(ga):
     m = ga.geodesic_mesh(9, reorder="hilbert")
     ei = torch.from_numpy(m.edge_index).to(DEV)
