@@ -111,6 +111,7 @@ SIGNATURES = {
     "gwen_gcn_linear_workspace_floats": (_i64, [_i64, _i64, _i64]),
     "gwen_gcn_linear_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp,
                                    _i64, _vp]),
+    "gwen_gcn_linear_nn_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "gwen_gcn_layer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                   _i64, _i64, _i64, _int, _int, _vp]),
     "gwen_gcn_layer_supported": (_int, [_i64, _i64]),

@@ -145,10 +145,45 @@ __device__ inline void slab_store(const float4_t (&v)[4], __bf16 *__restrict__ i
   }
 }
 
+// WT ("NN" products: the weight operand given as Wt [K, N] row-major -- the backward's gx = gh W with W as stored, no
+// transposing copy): a 32-deep x 128-column slab is read along N (consecutive lanes = consecutive columns, one dword per
+// k: coalesced) and parked as bf16x4 K-QUADS, image layout [8 quads][128 columns] -- writes and the two 8-byte fragment
+// reads of a lane (quads 2 mh, 2 mh + 1 of its column) both run over consecutive columns: conflict-free without padding.
+// One thread's share: 4 (quad, column) items, 4 dwords each.
+__device__ inline void slab_load_t(const float *__restrict__ wt, int64_t ld, int k0, int K, int col0, int ncols,
+                                   float4_t (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * kThreads;
+    const int n = idx & 127, kq = idx >> 7;
+    const int c = col0 + n;
+    const int cc = c < ncols ? c : ncols - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + 4 * kq + e;
+      const float t = wt[(int64_t)(k < K ? k : K - 1) * ld + cc];            // unconditional, clamped, zeroed by select
+      v[i][e] = (k < K && c < ncols) ? t : 0.0f;
+    }
+  }
+}
+template <int NS>
+__device__ inline void slab_store_t(const float4_t (&v)[4], __bf16 *__restrict__ img) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * kThreads;
+    const int n = idx & 127, kq = idx >> 7;
+    const float f4[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+    bf16x4 im[NS];
+    gwen::split_images<4, NS>(f4, im);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4 *>(img + s * 128 * SPB + (kq * 128 + n) * 4) = im[s];
+  }
+}
+
 // NCT = 16-column tiles per block (8: 128 columns; 4: 64 columns for narrow outputs).
 // The next slab's global loads are issued before the current slab's MFMAs and parked in LDS after
 // them, so their latency hides under the matrix work instead of standing in front of it.
-template <bool VEC, int NCT, int NS>
+template <bool VEC, int NCT, int NS, bool WT = false>
 __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restrict__ x,
                                                            const float *__restrict__ W,
                                                            const float *__restrict__ bias,
@@ -176,17 +211,20 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
   const bool partial = gridDim.z > 1;
   if (partial) h += (int64_t)blockIdx.z * rows * Fout;
   float4_t pa[4], pb[4];
+  const int ncol_end = col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout;
   slab_load<VEC>(x, ldx, row0, rows, k_lo, k_hi, pa);
-  slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout), k_lo, k_hi, pb);
+  if constexpr (WT) slab_load_t(W, Fout, k_lo, k_hi, col0, ncol_end, pb);
+  else slab_load<VEC>(W, Fin, col0, (int64_t)ncol_end, k_lo, k_hi, pb);
   slab_store<NS>(pa, aimg);
-  slab_store<NS>(pb, bimg);
+  if constexpr (WT) slab_store_t<NS>(pb, bimg);
+  else slab_store<NS>(pb, bimg);
   __syncthreads();
   for (int k0 = k_lo; k0 < k_hi; k0 += SBK) {
     const bool more = k0 + SBK < k_hi;
     // issued unconditionally (past the last slab the loads are clamped and their result unused)
     slab_load<VEC>(x, ldx, row0, rows, k0 + SBK, k_hi, pa);
-    slab_load<VEC>(W, Fin, col0, (int64_t)(col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout),
-                   k0 + SBK, k_hi, pb);
+    if constexpr (WT) slab_load_t(W, Fout, k0 + SBK, k_hi, col0, ncol_end, pb);
+    else slab_load<VEC>(W, Fin, col0, (int64_t)ncol_end, k0 + SBK, k_hi, pb);
     bf16x8 fa[2][NS];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -199,7 +237,15 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
       const int off = (ct * 16 + mi) * SPB + 8 * mh;
       bf16x8 fb[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) fb[s] = *reinterpret_cast<const bf16x8 *>(bimg + s * kImg + off);
+      for (int s = 0; s < NS; ++s) {
+        if constexpr (WT) {
+          const bf16x4 q0 = *reinterpret_cast<const bf16x4 *>(bimg + s * kImg + ((2 * mh) * 128 + ct * 16 + mi) * 4);
+          const bf16x4 q1 = *reinterpret_cast<const bf16x4 *>(bimg + s * kImg + ((2 * mh + 1) * 128 + ct * 16 + mi) * 4);
+          fb[s] = bf16x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        } else {
+          fb[s] = *reinterpret_cast<const bf16x8 *>(bimg + s * kImg + off);
+        }
+      }
       // terms (x image t - i) . (W image i), from the smallest to hi . hi (split.h's order with x as the A operand)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -212,7 +258,8 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
     __syncthreads();                       // every wave is done reading this slab
     if (more) {
       slab_store<NS>(pa, aimg);
-      slab_store<NS>(pb, bimg);
+      if constexpr (WT) slab_store_t<NS>(pb, bimg);
+      else slab_store<NS>(pb, bimg);
       __syncthreads();
     }
   }
@@ -344,5 +391,53 @@ extern "C" int gwen_gcn_linear_f32(const float *x, const float *W, const float *
   else
     k_linear<false><<<grid, kThreads, 0, st>>>(x, W, bias, h, rows, (int)Fin, (int)Fout, ldx, ldh, relu);
   GWEN_LAUNCH_CHECK();
+  return GWEN_OK;
+}
+
+// h = act(x Wt + bias) with the weight operand given as Wt [Fin, Fout] row-major ("NN"): the backward's gx = gh W with W
+// as the layer stores it ([out, in] = [K, N] of this product) -- no transposing copy (at the reference's own shape,
+// 16 384 x 1024 weights, torch's transposes were 88 us of a 1.2 ms training step) -- and out = D g for a dense
+// adjacency.  Split contractions only (bf16x3 / bf16x6; f16x3 = bf16x6 here); split-K as gwen_gcn_linear_f32.
+extern "C" int gwen_gcn_linear_nn_f32(const float *x, const float *Wt, const float *bias, float *h, int64_t rows,
+                                      int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldw, int64_t ldh, int relu,
+                                      int contract, float *workspace, int64_t workspace_floats, gwen_stream_t stream_) {
+  if (rows < 0 || Fin <= 0 || Fout < 0 || ldx < Fin || ldw < Fout || ldh < Fout) return GWEN_EINVAL;
+  if (contract != GWEN_CONTRACT_BF16X3 && contract != GWEN_CONTRACT_BF16X6 && contract != GWEN_CONTRACT_F16X3) return GWEN_EINVAL;
+  if (rows == 0 || Fout == 0) return GWEN_OK;
+  if (!h || !x || !Wt || x == h) return GWEN_EINVAL;
+  if (Fin >= (1 << 30) || Fout >= (1 << 30)) return GWEN_ERANGE;
+  const bool x6 = contract != GWEN_CONTRACT_BF16X3;
+  hipStream_t st = gwen_stream(stream_);
+  const bool vec = Fin % 4 == 0 && ldx % 4 == 0 && gwen_aligned(x, 16);
+  const int bn = Fout <= 64 ? 64 : SBN;
+  const int64_t sx = (rows + SBM - 1) / SBM, sy = (Fout + bn - 1) / bn;
+  if (sx > 0x7fffffffLL || sy > 65535) return GWEN_ERANGE;
+  int nsplit = splitk_factor(rows, Fin, Fout);
+  if (nsplit > 1 && (!workspace || workspace_floats < (int64_t)nsplit * rows * Fout)) nsplit = 1;
+  const int kchunk = nsplit > 1 ? (int)(((Fin + nsplit - 1) / nsplit + SBK - 1) / SBK * SBK) : (int)Fin;
+  const int nz = (int)((Fin + kchunk - 1) / kchunk);
+  dim3 sgrid((unsigned)sx, (unsigned)sy, (unsigned)nz);
+  float *dst = nz > 1 ? workspace : h;
+  const int64_t dld = nz > 1 ? Fout : ldh;
+  // (the kernel reads Wt with the row pitch it is given as "Fout": pass ldw through that argument when they differ)
+  if (ldw != Fout) return GWEN_EINVAL;
+#define GWEN_LT(V, T)                                                                                          \
+  do {                                                                                                         \
+    if (x6)                                                                                                    \
+      k_linear_split<V, T, 3, true><<<sgrid, kThreads, 0, st>>>(x, Wt, bias, dst, rows, (int)Fin, (int)Fout, ldx, dld, \
+                                                                relu, kchunk);                                 \
+    else                                                                                                       \
+      k_linear_split<V, T, 2, true><<<sgrid, kThreads, 0, st>>>(x, Wt, bias, dst, rows, (int)Fin, (int)Fout, ldx, dld, \
+                                                                relu, kchunk);                                 \
+  } while (0)
+  if (vec) { if (bn == 64) GWEN_LT(true, 4); else GWEN_LT(true, 8); }
+  else     { if (bn == 64) GWEN_LT(false, 4); else GWEN_LT(false, 8); }
+#undef GWEN_LT
+  GWEN_LAUNCH_CHECK();
+  if (nz > 1) {
+    const int64_t count = rows * Fout;
+    k_splitk_reduce<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(workspace, bias, h, rows, (int)Fout, ldh, nz, relu);
+    GWEN_LAUNCH_CHECK();
+  }
   return GWEN_OK;
 }

@@ -127,6 +127,33 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool 
     return out
 
 
+def linear_nn(x: Tensor, weight_t: Tensor, contract: Optional[str] = None) -> Tensor:
+    """K3 with the weight operand as stored by the OTHER product: x [..., K] @ weight_t [K, N] (row-major), no transposing
+    copy -- the backward's g_x = g W with W = the layer's [out, in] weight.  Split contractions ("3xbf16", "bf16x6",
+    "f16x3"); "fp32" / None transposes and takes the exact kernel."""
+    _require(x, "x")
+    _require(weight_t, "weight_t")
+    code = _dense_code(contract, True)
+    # (tall inputs -- mesh-sized rows -- keep the transposed form: their weights are small and K3 runs them on K8's pipeline)
+    if code == _lib.CONTRACT_F32 or math.prod(x.shape[:-1]) >= 16384:
+        return linear(x, weight_t.t().contiguous(), contract=contract)
+    x = x.contiguous()
+    weight_t = weight_t.contiguous()
+    k, n = weight_t.shape
+    if x.size(-1) != k:
+        raise ValueError(f"x has {x.size(-1)} features but weight_t has {k} rows")
+    rows = math.prod(x.shape[:-1])
+    out = torch.empty(*x.shape[:-1], n, dtype=torch.float32, device=x.device)
+    dev = x.device
+    nws = int(_lib.lib().gwen_gcn_linear_workspace_floats(rows, k, n))
+    ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws > 0 else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gwen_gcn_linear_nn_f32(_ptr(x), _ptr(weight_t), None, _ptr(out), rows, k, n, k, n, n, 0, code,
+                                               _ptr(ws), nws, _stream(dev))
+    _lib.check(rc, "gwen_gcn_linear_nn_f32")
+    return out
+
+
 class LinearFunction(torch.autograd.Function):
     """Differentiable K3: y = act(x W^T + b) with the backward on the same library -- g_x = g W (K3), g_W = g^T x and
     g_b = column sums of g (the fixed-order reductions of K4's backward).  ``act``: "none" or "relu"."""
@@ -144,7 +171,7 @@ class LinearFunction(torch.autograd.Function):
         g = g.contiguous()
         if ctx.relu:
             g = relu_backward(y, g)
-        gx = linear(g, weight.t().contiguous(), contract=ctx.contract) if ctx.needs_input_grad[0] else None
+        gx = linear_nn(g, weight, ctx.contract) if ctx.needs_input_grad[0] else None
         gw = grad_weight(g, x, ctx.contract) if ctx.needs_input_grad[1] else None
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None
@@ -503,12 +530,12 @@ class GCNLayerFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in, ctx.contract)       # gh^T x
             if ctx.needs_input_grad[0]:
-                gx = linear(gh, weight.t().contiguous(), contract=ctx.contract)        # gh W (split-K)
+                gx = linear_nn(gh, weight, ctx.contract)                                 # gh W (split-K, W as stored)
         else:
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(g, saved_in, ctx.contract)        # g^T (A~ x)
             if ctx.needs_input_grad[0]:
-                gagg = linear(g, weight.t().contiguous(), contract=ctx.contract)       # g W
+                gagg = linear_nn(g, weight, ctx.contract)                                # g W
                 gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)
         return gx, gw, gb, None, None, None, None
 

@@ -171,6 +171,13 @@ int64_t gwen_gcn_linear_workspace_floats(int64_t rows, int64_t Fin, int64_t Fout
 int gwen_gcn_linear_f32(const float *x, const float *W, const float *bias, float *h, int64_t rows,
                         int64_t Fin, int64_t Fout, int64_t ldx, int64_t ldh, int relu, int exact,
                         float *workspace, int64_t workspace_floats, gwen_stream_t stream);
+/* The same product with the weight operand given as Wt [Fin, Fout] row-major ("NN"): h = act(x Wt + bias).  The
+ * backward's gx = gh W with W as the layer stores it ([out, in] of the forward = [K, N] here), without a transposing
+ * copy; out = D g for a dense adjacency D.  Split contractions only (GWEN_CONTRACT_BF16X3 / BF16X6; F16X3 = BF16X6
+ * here), ldw == Fout, x != h; workspace as gwen_gcn_linear_f32 (split-K). */
+int gwen_gcn_linear_nn_f32(const float *x, const float *Wt, const float *bias, float *h, int64_t rows, int64_t Fin,
+                           int64_t Fout, int64_t ldx, int64_t ldw, int64_t ldh, int relu, int contract,
+                           float *workspace, int64_t workspace_floats, gwen_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  one whole GCNConv layer (+ReLU) in a single launch, aggregate-first:

@@ -761,6 +761,27 @@ def test_layer_bwd_leaves_the_bias_sums_of_the_layer_below(ga, fg, fx, members):
         assert rel_err(part[:nch].double().sum(0), gx.double().sum((0, 1))) <= 2e-6
 
 
+@pytest.mark.parametrize("rows,k,n", [(125, 1024, 16384), (125, 16384, 1024), (300, 20, 48), (1000, 64, 64), (7, 125, 512),
+                                      (129, 256, 100), (1, 32, 16), (513, 96, 130)])
+def test_linear_nn_weight_as_stored(ga, rows, k, n):
+    """ops.linear_nn = x [rows, K] @ Wt [K, N] with Wt row-major -- the backward's g W without a transposing copy
+    (gwen_gcn_linear_nn_f32): the reference's own shapes (split-K over 16 384), widths that are no multiple of 4 or of a
+    tile, one row; both splits against fp64, and bitwise the transposed form's result is NOT required (another slab
+    order) but the same bar is."""
+    from gwen_amd import ops
+    gen = torch.Generator().manual_seed(SEED + rows + k)
+    x = torch.randn(rows, k, generator=gen).to(DEV)
+    wt = (torch.randn(k, n, generator=gen) / k ** 0.5).to(DEV)
+    want = x.double() @ wt.double()
+    # ("fp32": the transposed exact kernel, a k-ordered fp32 fmaf chain -- its rounding grows with the 16 384-long sum)
+    for contract, tol in (("bf16x6", 2e-6), ("f16x3", 2e-6), ("3xbf16", 3e-5), ("fp32", 2e-6 if k <= 1024 else 1e-5)):
+        got = ops.linear_nn(x, wt, contract)
+        assert got.shape == (rows, n)
+        assert rel_err(got, want) <= tol, (contract, rel_err(got, want))
+        assert torch.equal(got, ops.linear_nn(x, wt, contract))
+        assert rel_err(got, ops.linear(x, wt.t().contiguous(), contract=contract)) <= tol
+
+
 def test_stack_backward_without_input_grad_and_determinism(ga):
     m = ga.geodesic_mesh(9, reorder="hilbert")
     ei = torch.from_numpy(m.edge_index).to(DEV)
