@@ -180,10 +180,45 @@ __device__ inline void slab_store_t(const float4_t (&v)[4], __bf16 *__restrict__
   }
 }
 
+// ... and with 16-byte loads (Fout % 4 == 0, Wt 16-byte aligned): a thread owns ONE k-quad of four consecutive columns --
+// four float4 loads (32 lanes = 512 contiguous bytes of a row of Wt: the dword form above is one 256-byte instruction per
+// k and was instruction-bound, 2.7 x slower than the transposed product it replaces), turned 4 x 4 in registers, parked as
+// 32 contiguous bytes of the quad's row.
+__device__ inline void slab_load_tv(const float *__restrict__ wt, int64_t ld, int k0, int K, int col0, int ncols,
+                                    float4_t (&v)[4]) {
+  const int kq = threadIdx.x >> 5, n4 = (threadIdx.x & 31) * 4;
+  const int c = col0 + n4;
+  const int cc = c < ncols ? c : 0;                     // (ncols % 4 == 0: a quad of columns is inside or outside as a whole)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = k0 + 4 * kq + e;
+    const float4_t t = *reinterpret_cast<const float4_t *>(wt + (int64_t)(k < K ? k : K - 1) * ld + cc);
+    v[e] = (k < K && c < ncols) ? t : float4_t{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NS>
+__device__ inline void slab_store_tv(const float4_t (&v)[4], __bf16 *__restrict__ img) {
+  const int kq = threadIdx.x >> 5, n4 = (threadIdx.x & 31) * 4;
+  bf16x4 im[4][NS];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float f4[4] = {v[0][j], v[1][j], v[2][j], v[3][j]};
+    gwen::split_images<4, NS>(f4, im[j]);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    __bf16 *dst = img + s * 128 * SPB + (kq * 128 + n4) * 4;
+    *reinterpret_cast<bf16x8 *>(dst) = bf16x8{im[0][s][0], im[0][s][1], im[0][s][2], im[0][s][3],
+                                              im[1][s][0], im[1][s][1], im[1][s][2], im[1][s][3]};
+    *reinterpret_cast<bf16x8 *>(dst + 8) = bf16x8{im[2][s][0], im[2][s][1], im[2][s][2], im[2][s][3],
+                                                  im[3][s][0], im[3][s][1], im[3][s][2], im[3][s][3]};
+  }
+}
+
 // NCT = 16-column tiles per block (8: 128 columns; 4: 64 columns for narrow outputs).
 // The next slab's global loads are issued before the current slab's MFMAs and parked in LDS after
 // them, so their latency hides under the matrix work instead of standing in front of it.
-template <bool VEC, int NCT, int NS, bool WT = false>
+template <bool VEC, int NCT, int NS, int WT = 0>      // WT: 0 W [Fout, Fin]; 1 Wt [Fin, Fout], dword loads; 2 ..., 16-byte loads
 __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restrict__ x,
                                                            const float *__restrict__ W,
                                                            const float *__restrict__ bias,
@@ -213,17 +248,20 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
   float4_t pa[4], pb[4];
   const int ncol_end = col0 + NCT * 16 < Fout ? col0 + NCT * 16 : Fout;
   slab_load<VEC>(x, ldx, row0, rows, k_lo, k_hi, pa);
-  if constexpr (WT) slab_load_t(W, Fout, k_lo, k_hi, col0, ncol_end, pb);
+  if constexpr (WT == 2) slab_load_tv(W, Fout, k_lo, k_hi, col0, ncol_end, pb);
+  else if constexpr (WT == 1) slab_load_t(W, Fout, k_lo, k_hi, col0, ncol_end, pb);
   else slab_load<VEC>(W, Fin, col0, (int64_t)ncol_end, k_lo, k_hi, pb);
   slab_store<NS>(pa, aimg);
-  if constexpr (WT) slab_store_t<NS>(pb, bimg);
+  if constexpr (WT == 2) slab_store_tv<NS>(pb, bimg);
+  else if constexpr (WT == 1) slab_store_t<NS>(pb, bimg);
   else slab_store<NS>(pb, bimg);
   __syncthreads();
   for (int k0 = k_lo; k0 < k_hi; k0 += SBK) {
     const bool more = k0 + SBK < k_hi;
     // issued unconditionally (past the last slab the loads are clamped and their result unused)
     slab_load<VEC>(x, ldx, row0, rows, k0 + SBK, k_hi, pa);
-    if constexpr (WT) slab_load_t(W, Fout, k0 + SBK, k_hi, col0, ncol_end, pb);
+    if constexpr (WT == 2) slab_load_tv(W, Fout, k0 + SBK, k_hi, col0, ncol_end, pb);
+    else if constexpr (WT == 1) slab_load_t(W, Fout, k0 + SBK, k_hi, col0, ncol_end, pb);
     else slab_load<VEC>(W, Fin, col0, (int64_t)ncol_end, k0 + SBK, k_hi, pb);
     bf16x8 fa[2][NS];
 #pragma unroll
@@ -238,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
       bf16x8 fb[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        if constexpr (WT) {
+        if constexpr (WT != 0) {
           const bf16x4 q0 = *reinterpret_cast<const bf16x4 *>(bimg + s * kImg + ((2 * mh) * 128 + ct * 16 + mi) * 4);
           const bf16x4 q1 = *reinterpret_cast<const bf16x4 *>(bimg + s * kImg + ((2 * mh + 1) * 128 + ct * 16 + mi) * 4);
           fb[s] = bf16x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
@@ -258,7 +296,8 @@ __global__ __launch_bounds__(kThreads) void k_linear_split(const float *__restri
     __syncthreads();                       // every wave is done reading this slab
     if (more) {
       slab_store<NS>(pa, aimg);
-      if constexpr (WT) slab_store_t<NS>(pb, bimg);
+      if constexpr (WT == 2) slab_store_tv<NS>(pb, bimg);
+      else if constexpr (WT == 1) slab_store_t<NS>(pb, bimg);
       else slab_store<NS>(pb, bimg);
       __syncthreads();
     }
@@ -421,17 +460,20 @@ extern "C" int gwen_gcn_linear_nn_f32(const float *x, const float *Wt, const flo
   const int64_t dld = nz > 1 ? Fout : ldh;
   // (the kernel reads Wt with the row pitch it is given as "Fout": pass ldw through that argument when they differ)
   if (ldw != Fout) return GWEN_EINVAL;
-#define GWEN_LT(V, T)                                                                                          \
+  const bool wvec = Fout % 4 == 0 && gwen_aligned(Wt, 16);
+#define GWEN_LT(V, T, WV)                                                                                      \
   do {                                                                                                         \
     if (x6)                                                                                                    \
-      k_linear_split<V, T, 3, true><<<sgrid, kThreads, 0, st>>>(x, Wt, bias, dst, rows, (int)Fin, (int)Fout, ldx, dld, \
-                                                                relu, kchunk);                                 \
+      k_linear_split<V, T, 3, WV><<<sgrid, kThreads, 0, st>>>(x, Wt, bias, dst, rows, (int)Fin, (int)Fout, ldx, dld, \
+                                                              relu, kchunk);                                   \
     else                                                                                                       \
-      k_linear_split<V, T, 2, true><<<sgrid, kThreads, 0, st>>>(x, Wt, bias, dst, rows, (int)Fin, (int)Fout, ldx, dld, \
-                                                                relu, kchunk);                                 \
+      k_linear_split<V, T, 2, WV><<<sgrid, kThreads, 0, st>>>(x, Wt, bias, dst, rows, (int)Fin, (int)Fout, ldx, dld, \
+                                                              relu, kchunk);                                   \
   } while (0)
-  if (vec) { if (bn == 64) GWEN_LT(true, 4); else GWEN_LT(true, 8); }
-  else     { if (bn == 64) GWEN_LT(false, 4); else GWEN_LT(false, 8); }
+#define GWEN_LT2(V, T) do { if (wvec) GWEN_LT(V, T, 2); else GWEN_LT(V, T, 1); } while (0)
+  if (vec) { if (bn == 64) GWEN_LT2(true, 4); else GWEN_LT2(true, 8); }
+  else     { if (bn == 64) GWEN_LT2(false, 4); else GWEN_LT2(false, 8); }
+#undef GWEN_LT2
 #undef GWEN_LT
   GWEN_LAUNCH_CHECK();
   if (nz > 1) {

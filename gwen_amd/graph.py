@@ -50,6 +50,7 @@ class GraphCSR:
     _transposed: Optional[Tuple[Tensor, Tensor, Tensor]] = field(default=None, repr=False)
     _grouped: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = field(default=None, repr=False)
     _dense: Optional[Tensor] = field(default=None, repr=False)
+    _dense_tsq: Optional[Tensor] = field(default=None, repr=False)
     _tiles: Optional[tuple] = field(default=None, repr=False)
     _tgraph: Optional["GraphCSR"] = field(default=None, repr=False)
     _levels: Optional[tuple] = field(default=None, repr=False)
@@ -205,6 +206,18 @@ class GraphCSR:
             _lib.check(rc, "gwen_gcn_dense_f32")
             self._dense = d
         return self._dense
+
+    def dense_transposed_square(self) -> Optional[Tensor]:
+        """A~^T as a contiguous [N, N] fp32 matrix (square graphs of at most 256 nodes, as ``dense``): the backward's
+        gh = A~^T g as ONE dense product on such graphs (ops.linear_nn) instead of K2 walking 125-entry rows.  Cached."""
+        if self.num_src >= 0 or not 1 <= self.num_nodes <= 256:
+            return None
+        if self._dense_tsq is None:
+            n = self.num_nodes
+            d = self.transposed_graph().dense()
+            np_ = int(_lib.lib().gwen_gcn_small_pad(n))
+            self._dense_tsq = d.view(np_, np_)[:n, :n].contiguous()
+        return self._dense_tsq
 
     def transposed(self) -> Tuple[Tensor, Tensor, Tensor]:
         """CSR by SOURCE node (rowptr [source_nodes + 1], col = target, val) for the backward pass; built on

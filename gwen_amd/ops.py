@@ -459,6 +459,17 @@ def relu_backward(y: Tensor, g: Tensor) -> Tensor:
     return out
 
 
+def _propagate_transposed(graph: GraphCSR, g: Tensor, contract: Optional[str]) -> Tensor:
+    """A~^T g for the backward.  Small square graphs with wide rows (the reference's member graphs: 125 nodes x 1024 ..
+    16 384 features) on a split precision: ONE dense product D^T g (K3 with g as the [K, N] operand, as the forward's K7
+    contracts D h) instead of K2 walking the 125-entry rows (53.6 -> 10 us at 16 384 features); everything else: K2."""
+    if g.dim() == 2 and g.size(-1) >= 256 and contract in ("3xbf16", "bf16x6", "f16x3"):
+        d = graph.dense_transposed_square()
+        if d is not None:
+            return linear_nn(d, g, contract)
+    return propagate(graph, g, transposed=True)
+
+
 class GCNLayerFunction(torch.autograd.Function):
     """act(A~ (x W^T) + b): forward and backward entirely on the HIP kernels.
 
@@ -526,7 +537,7 @@ class GCNLayerFunction(torch.autograd.Function):
         gb = grad_bias(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         gx = gw = None
         if ctx.order in ("transform_first", "fused", "fused_x3", "fused_exact", "small", "wide"):   # out = act(A~ x W^T + b) either way
-            gh = propagate(ctx.graph, g, transposed=True)          # A~^T g
+            gh = _propagate_transposed(ctx.graph, g, ctx.contract)  # A~^T g
             if ctx.needs_input_grad[1]:
                 gw = grad_weight(gh, saved_in, ctx.contract)       # gh^T x
             if ctx.needs_input_grad[0]:
@@ -536,7 +547,7 @@ class GCNLayerFunction(torch.autograd.Function):
                 gw = grad_weight(g, saved_in, ctx.contract)        # g^T (A~ x)
             if ctx.needs_input_grad[0]:
                 gagg = linear_nn(g, weight, ctx.contract)                                # g W
-                gx = propagate(ctx.graph, gagg, transposed=True)   # A~^T (g W)
+                gx = _propagate_transposed(ctx.graph, gagg, ctx.contract)   # A~^T (g W)
         return gx, gw, gb, None, None, None, None
 
 
