@@ -137,6 +137,30 @@ def test_training_step_through_k7_matches_the_oracle(ga):
     assert rel_err(conv.bias.grad, ref.bias.grad) <= REL_TOL
 
 
+@pytest.mark.parametrize("name,n,ei", [c for c in SMALL if c[1] >= 2], ids=[c[0] for c in SMALL if c[1] >= 2])
+@pytest.mark.parametrize("f", [256, 1024])
+def test_backward_propagate_as_one_dense_product(ga, name, n, ei, f):
+    """ops._propagate_transposed: on square graphs of at most 256 nodes with wide rows the backward's gh = A~^T g is ONE
+    dense product D^T g (K3 with g as the [K, N] operand, ops.linear_nn) -- against K2 over the transposed CSR (the exact,
+    sequential sum) and the fp64 oracle's A~^T g; narrow rows and the fp32 precision stay on K2 (bitwise)."""
+    from gwen_amd import ops
+    from oracle import gcn_oracle as O
+    g = ga.prepare_graph(ei.to(DEV), n)
+    grad = torch.randn(n, f, generator=torch.Generator().manual_seed(SEED + n)).to(DEV)
+    exact = ops.propagate(g, grad, transposed=True)
+    for contract, tol in (("bf16x6", 2e-6), ("f16x3", 2e-6), ("3xbf16", 3e-5)):
+        got = ops._propagate_transposed(g, grad, contract)
+        assert rel_err(got, exact) <= tol, (contract, rel_err(got, exact))
+        assert torch.equal(got, ops._propagate_transposed(g, grad, contract))
+    assert torch.equal(ops._propagate_transposed(g, grad, "fp32"), exact)
+    assert torch.equal(ops._propagate_transposed(g, grad[:, :64].contiguous(), "bf16x6"),
+                       ops.propagate(g, grad[:, :64].contiguous(), transposed=True))
+    dense = g.dense_transposed_square()
+    assert dense is not None and dense.shape == (n, n)
+    want = dense.double() @ grad.double()
+    assert rel_err(exact, want) <= 1e-6
+
+
 def test_weighted_small_graph(ga):
     """Explicit edge weights (and improved=True, which only acts on weighted graphs) reach K7 through
     the dense matrix."""
