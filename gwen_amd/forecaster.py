@@ -22,7 +22,7 @@ computed once per ``forward`` / ``rollout`` call.  Trainable (``interaction._Int
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 import torch
@@ -108,14 +108,15 @@ class InteractionForecaster(nn.Module):
         return (lin(graphs.mesh_pos, self.mesh_embed), lin(graphs.f_g2m, self.g2m_edge_embed),
                 lin(graphs.f_mesh, self.mesh_edge_embed), lin(graphs.f_m2g, self.m2g_edge_embed))
 
-    def _step(self, grid_x: Tensor, graphs: ForecastGraphs, static) -> Tensor:
+    def _step(self, grid_x: Tensor, graphs: ForecastGraphs, static, out: Optional[Tensor] = None) -> Tensor:
         vm, e_g2m, e_m, e_m2g = static
         vg = self._lin(grid_x, self.grid_embed)
         vm, _ = self.encoder(vg, vm, e_g2m, graphs.g2m, update_edges=False)
         for net in self.processor:
             vm, e_m = net(vm, vm, e_m, graphs.mesh)
         vg, _ = self.decoder(vm, vg, e_m2g, graphs.m2g, update_edges=False)
-        return grid_x + self._lin(vg, self.readout)
+        delta = self._lin(vg, self.readout)
+        return grid_x + delta if out is None else torch.add(grid_x, delta, out=out)      # (out: GraphedStep's buffers)
 
     def forward(self, grid_x: Tensor, graphs: ForecastGraphs) -> Tensor:
         """``grid_x`` [N_grid, C] or [members, N_grid, C] (members share graphs and weights: one launch set
@@ -137,8 +138,8 @@ class InteractionForecaster(nn.Module):
             if graphed:
                 step = GraphedStep(self, graphs, grid_x)
                 for _ in range(n_steps):
-                    cur = step(cur).clone()
-                    states.append(cur)
+                    cur = step(cur)                          # (one of the step's two buffers: the next call reads it in place)
+                    states.append(cur.clone())
                 return states
             static = self._static(graphs)
             for _ in range(n_steps):
@@ -181,8 +182,9 @@ def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
             cur = x_members.reshape(-1, x_members.size(-1))
             if graphed:
                 step = captured(gb, cur)
-                for _ in range(n_steps):
-                    cur = step(cur).clone()
+                for _ in range(n_steps):             # (the step alternates between its two state buffers: no copies)
+                    cur = step(cur)
+                cur = cur.clone()
             else:
                 static = model._static(gb)
                 for _ in range(n_steps):
@@ -195,8 +197,8 @@ def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
             for m in range(m_local):
                 cur = x_members[m]
                 for _ in range(n_steps):
-                    cur = step(cur).clone() if step is not None else model._step(cur, graphs, static)
-                finals.append(cur)
+                    cur = step(cur) if step is not None else model._step(cur, graphs, static)
+                finals.append(cur.clone() if step is not None else cur)
             local = torch.stack(finals)
     if not gather:
         return local
@@ -204,22 +206,31 @@ def ensemble_forecast(model, graphs: ForecastGraphs, x_members: Tensor,
 
 
 class GraphedStep:
-    """One forecaster step captured into a hipGraph (``torch.cuda.CUDAGraph``): ``step(x)`` copies ``x``
-    into the static input, replays, and returns the static output (clone it to keep it)."""
+    """One forecaster step captured into hipGraphs (``torch.cuda.CUDAGraph``) over TWO state buffers -- the graph A -> B
+    and the graph B -> A -- so that an autoregressive rollout replays them alternately without copying the state (one
+    capture over a fixed input / output pair cost two state-sized copies per step: 2 % of the c5 rollout).  ``step(x)``
+    copies ``x`` into the next input buffer unless it IS that buffer (the previous call's result), replays, and returns the
+    output buffer -- valid until the call AFTER the next one (clone it to keep it longer)."""
 
     def __init__(self, model: InteractionForecaster, graphs: ForecastGraphs, grid_x: Tensor):
-        self.x = grid_x.detach().clone()
-        self.graphs = graphs                                 # the graph holds raw pointers into these:
-        with torch.no_grad():                                # keep every tensor it reads alive
+        self.bufs = [grid_x.detach().clone(), torch.empty_like(grid_x)]
+        self.graphs = graphs                                 # the captured graphs hold raw pointers into these:
+        self.cur = 0                                         # the buffer the next call reads
+        with torch.no_grad():                                # keep every tensor they read alive
             static = self._static = model._static(graphs)
-            model._step(self.x, graphs, static)             # warm-up: occupancy queries, tilings, caches
-            torch.cuda.synchronize(self.x.device)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.y = model._step(self.x, graphs, static)
+            model._step(self.bufs[0], graphs, static, out=self.bufs[1])       # warm-up: occupancy queries, tilings, caches
+            torch.cuda.synchronize(grid_x.device)
+            self.replays = []
+            for i in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    model._step(self.bufs[i], graphs, static, out=self.bufs[1 - i])
+                self.replays.append(g)
 
     def __call__(self, x: Tensor) -> Tensor:
-        if x.data_ptr() != self.x.data_ptr():
-            self.x.copy_(x)
-        self.graph.replay()
-        return self.y
+        src = self.bufs[self.cur]
+        if x.data_ptr() != src.data_ptr():
+            src.copy_(x)
+        self.replays[self.cur].replay()
+        self.cur ^= 1
+        return self.bufs[self.cur]
